@@ -200,11 +200,11 @@ int32_t rt_path_accumulate_device(rt_ctx* ctx, const rt_scene* scene, const rt_c
 int32_t rt_whitted_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* camera,
                           const rt_whitted_params* params, int32_t width, int32_t height,
                           float* d_color, void* stream);
-/* The tail of Render: c = accum.rgb * scale; gamma ? sqrt(c) : c; clamp to [0,1];
- * truncate(c*255) -> B,G,R,255 (03 Main.cpp:352-367; 01 Main.cpp:351-356 with gamma=0, scale=1).
+/* The tail of Render: c = accum.rgb / divisor; gamma ? sqrt(c) : c; clamp to [0,1];
+ * truncate(c*255) -> B,G,R,255 (03 Main.cpp:352-367; 01 Main.cpp:351-356 with gamma=0, divisor=1).
  * d_rgb (optional) receives the linear float RGB (3 floats per pixel). */
 int32_t rt_resolve_device(rt_ctx* ctx, const float* d_accum, int32_t width, int32_t height,
-                          float scale, int32_t gamma, uint8_t* d_bgra, int32_t bgra_stride_bytes,
+                          float divisor, int32_t gamma, uint8_t* d_bgra, int32_t bgra_stride_bytes,
                           float* d_rgb, void* stream);
 int32_t rt_sync(rt_ctx* ctx, void* stream);
 

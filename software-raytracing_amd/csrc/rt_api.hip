@@ -1,0 +1,400 @@
+// rt_api.hip - host side of librt_mi355.so: the extern "C" entry points of include/rt_mi355.h.
+// Flattens and precomputes the scene (what the reference recomputes per ray: rotation matrices
+// of Rectangle, r*r, n.p0, the hemisphere cone cosine), uploads it, launches the kernels of
+// rt_kernels.hip on a HIP stream and reads results back.  No CPU tracing path exists here:
+// without a gfx950 device every render call fails with RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = n + n / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_pending = false;
+    DevBuf scene_buf, partial, accum, bgra, rgb;
+    unsigned long long* d_counters = nullptr;     // [0] rays, [1] shadow rays
+    unsigned long long* h_counters = nullptr;     // pinned
+    void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned scene staging
+    uint64_t pending_samples = 0;
+    rt_stats stats{};
+    std::string err;
+    int regen_threshold_override = -1;
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// math::GetRotationMat (Common/Math.hpp:913-930): Euler degrees -> 3x3, row-major out[9].
+void rotation_mat(const float deg[3], float out[9]) {
+    const double k = 3.14159265358979323846 / 180.0f;
+    float ax = (float)(deg[0] * k), ay = (float)(deg[1] * k), az = (float)(deg[2] * k);
+    float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
+    // columns i, j, k of the reference constructor; storage is row-major (Math.hpp:401-406)
+    float i[3] = {cz * cy, sz * cy, -sy};
+    float j[3] = {cz * sy * sx - sz * cx, sz * sy * sx + cz * cx, cy * sx};
+    float kk[3] = {cz * sy * cx + sz * sx, sz * sy * cx - cz * sx, cy * cx};
+    for (int r = 0; r < 3; ++r) { out[3 * r] = i[r]; out[3 * r + 1] = j[r]; out[3 * r + 2] = kk[r]; }
+}
+
+struct HostScene {
+    std::vector<int4> runs, info;
+    std::vector<float4> geom, mats, lights;
+};
+
+float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+
+// Validates rt_scene and builds the device layout documented in rt_device.h.
+int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/, HostScene& H) {
+    if (!s || s->n_prims < 0 || s->n_materials < 0 || s->n_lights < 0) return fail(c, RT_ERR_BAD_ARG, "scene: null or negative count");
+    if ((s->n_prims && !s->prims) || (s->n_materials && !s->materials) || (s->n_lights && !s->lights))
+        return fail(c, RT_ERR_BAD_ARG, "scene: null array with non-zero count");
+    for (int m = 0; m < s->n_materials; ++m) {
+        const rt_material& M = s->materials[m];
+        float4 m0 = f4(M.albedo[0], M.albedo[1], M.albedo[2], 0), m1 = f4(M.specular_intensity, M.shininess, M.primary_to_secondary, M.reflect_to_refract);
+        float4 m2 = f4(M.refraction_eta, 0, M.refraction_index, 0);
+        int type;
+        switch (M.type) {
+        case RT_MAT_PHONG: type = MAT_PHONG; break;
+        case RT_MAT_DIFFUSE: type = MAT_DIFFUSE;
+            m2.y = (variant == 3) ? 90.0f / 57.2958f : cosf(90.0f / 57.2958f); break;                  // 03 Utils.h:82, 04 Utils.h:141
+        case RT_MAT_METAL: type = MAT_METAL;
+            if (variant == 3) m2.y = (M.roughness > 0.0f) ? (60.0f * M.roughness) / 57.2958f : -1.0f;   // 03 Materials.hpp:152-154
+            else m2.y = cosf((60.0f * M.roughness) / 57.2958f); break;                                   // 04 Metal.hpp:76
+        case RT_MAT_DIELECTRIC: { type = MAT_DIELECTRIC;
+            float ratio = 1.0f / M.refraction_index;                                                    // Schlick r0, 04 Refractive.hpp:24-25
+            float r0 = (1.0f - ratio) / (1.0f + ratio);
+            m2.w = r0 * r0; m0.x = 1.0f / M.refraction_index; break; }
+        case RT_MAT_LIGHT: type = MAT_LIGHT; break;
+        default: return fail(c, RT_ERR_UNSUPPORTED, "material " + std::to_string(m) + ": unknown type " + std::to_string(M.type));
+        }
+        if (variant == 0 && type != MAT_PHONG) return fail(c, RT_ERR_UNSUPPORTED, "whitted render needs RT_MAT_PHONG materials (material " + std::to_string(m) + ")");
+        if (variant != 0 && type == MAT_PHONG) return fail(c, RT_ERR_UNSUPPORTED, "path render cannot shade RT_MAT_PHONG (material " + std::to_string(m) + ")");
+        m0.w = __builtin_bit_cast(float, type);
+        H.mats.push_back(m0); H.mats.push_back(m1); H.mats.push_back(m2);
+    }
+    // material slot n_materials: "no material".  Whitted: SceneElement's default (01 Types.h:51-58); path: black (04 Main.cpp:489-492)
+    {
+        int type = variant == 0 ? MAT_PHONG : MAT_NONE;
+        H.mats.push_back(f4(1, 1, 1, __builtin_bit_cast(float, type))); H.mats.push_back(f4(0.0f, 16.0f, 1.0f, 1.0f)); H.mats.push_back(f4(1.0f, 0, 1.0f, 0));
+    }
+    for (int i = 0; i < s->n_prims; ++i) {
+        const rt_prim& P = s->prims[i];
+        if (P.material >= s->n_materials) return fail(c, RT_ERR_BAD_ARG, "prim " + std::to_string(i) + ": material index out of range");
+        int mat = P.material < 0 ? s->n_materials : P.material;
+        int gi = (int)H.geom.size();
+        const float* f = P.f;
+        switch (P.type) {
+        case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], f[3])); break;
+        case RT_PRIM_PLANE:  H.geom.push_back(f4(f[3], f[4], f[5], f[3] * f[0] + f[4] * f[1] + f[5] * f[2])); break;
+        case RT_PRIM_RECT: {
+            if (variant == 0) return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles exist only in the path-tracing examples");
+            float neg[3] = {-f[5], -f[6], -f[7]}, pos[3] = {f[5], f[6], f[7]}, ri[9], rf[9];
+            rotation_mat(neg, ri); rotation_mat(pos, rf);                                               // Rectangle.hpp:58, :92
+            H.geom.push_back(f4(ri[0], ri[1], ri[2], f[0])); H.geom.push_back(f4(ri[3], ri[4], ri[5], f[1])); H.geom.push_back(f4(ri[6], ri[7], ri[8], f[2]));
+            H.geom.push_back(f4(f[3] / 2.0f, f[4] / 2.0f, rf[2], rf[5])); H.geom.push_back(f4(rf[8], 0, 0, 0));
+            break; }
+        case RT_PRIM_TRIANGLE: {
+            float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
+            float n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};   // cross(e2,e1), Ray.hpp:159
+            float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (float& v : n) v = len > 0 ? v / len : 0.0f;
+            // Inverse of the matrix with COLUMNS e2, e1, n (Ray.hpp:190, Math.hpp:635-654); rows 0 and 1 are needed
+            float m[9] = {e2[0], e1[0], n[0], e2[1], e1[1], n[1], e2[2], e1[2], n[2]};
+            float det = m[0] * m[4] * m[8] + m[1] * m[5] * m[6] + m[2] * m[3] * m[7] - m[2] * m[4] * m[6] - m[0] * m[5] * m[7] - m[1] * m[3] * m[8];
+            float di = det != 0 ? 1 / det : 0.0f;
+            float r0[3] = {(m[4] * m[8] - m[7] * m[5]) * di, (m[2] * m[7] - m[1] * m[8]) * di, (m[1] * m[5] - m[2] * m[4]) * di};
+            float r1[3] = {(m[5] * m[6] - m[3] * m[8]) * di, (m[0] * m[8] - m[2] * m[6]) * di, (m[3] * m[2] - m[0] * m[5]) * di};
+            if (det == 0) { r0[0] = r0[1] = r0[2] = -1.0f; }   // degenerate: Inverse returns zeros, (0,0) passes in the reference; keep it out here
+            H.geom.push_back(f4(n[0], n[1], n[2], n[0] * f[0] + n[1] * f[1] + n[2] * f[2]));
+            H.geom.push_back(f4(f[0], f[1], f[2], 0)); H.geom.push_back(f4(r0[0], r0[1], r0[2], 0)); H.geom.push_back(f4(r1[0], r1[1], r1[2], 0));
+            break; }
+        default: return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": unknown type " + std::to_string(P.type));
+        }
+        H.info.push_back(make_int4(P.type, gi, mat, (int)P.flags));
+        if (!H.runs.empty() && H.runs.back().x == P.type) H.runs.back().z++;
+        else H.runs.push_back(make_int4(P.type, gi, 1, i));
+    }
+    for (int l = 0; l < s->n_lights; ++l) {
+        const rt_light& L = s->lights[l];
+        H.lights.push_back(f4(L.position[0], L.position[1], L.position[2], L.radius)); H.lights.push_back(f4(L.color[0], L.color[1], L.color[2], 0));
+    }
+    return RT_OK;
+}
+
+// Packs the HostScene into one pinned blob, uploads it and fills DevScene with device pointers.
+int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
+    auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    size_t o_runs = 0, o_geom = pad(o_runs + H.runs.size() * 16), o_info = pad(o_geom + H.geom.size() * 16),
+           o_mats = pad(o_info + H.info.size() * 16), o_lights = pad(o_mats + H.mats.size() * 16), total = pad(o_lights + H.lights.size() * 16 + 16);
+    if (total > c->h_stage_cap) {
+        if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+        c->h_stage = nullptr; c->h_stage_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_stage, total * 2, hipHostMallocDefault));
+        c->h_stage_cap = total * 2;
+    }
+    HIPCHK(c, c->scene_buf.reserve(total));
+    // the staging blob may still be in flight from the previous call on this stream
+    HIPCHK(c, hipStreamSynchronize(st));
+    char* h = (char*)c->h_stage;
+    memcpy(h + o_runs, H.runs.data(), H.runs.size() * 16); memcpy(h + o_geom, H.geom.data(), H.geom.size() * 16);
+    memcpy(h + o_info, H.info.data(), H.info.size() * 16); memcpy(h + o_mats, H.mats.data(), H.mats.size() * 16);
+    memcpy(h + o_lights, H.lights.data(), H.lights.size() * 16);
+    HIPCHK(c, hipMemcpyAsync(c->scene_buf.p, h, total, hipMemcpyHostToDevice, st));
+    char* d = (char*)c->scene_buf.p;
+    D.runs = (const int4*)(d + o_runs); D.geom = (const float4*)(d + o_geom); D.info = (const int4*)(d + o_info);
+    D.mats = (const float4*)(d + o_mats); D.lights = (const float4*)(d + o_lights);
+    D.n_runs = (int)H.runs.size(); D.n_prims = (int)H.info.size(); D.n_mats = (int)H.mats.size() / 3; D.n_lights = (int)H.lights.size() / 2;
+    return RT_OK;
+}
+
+int begin_timed(rt_ctx* c, hipStream_t st) {
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    return RT_OK;
+}
+int end_timed(rt_ctx* c, hipStream_t st) {
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    c->timing_pending = true;
+    return RT_OK;
+}
+
+int check_ctx(rt_ctx* c) {
+    if (!c) return RT_ERR_BAD_ARG;
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int pick_slices(int width, int height, int n_samples) {
+    // enough threads to fill 256 CUs x 2048 lanes several times over; one slice at 4K
+    long long pixels = (long long)width * height;
+    long long target = 4LL * 256 * 2048;
+    int s = (int)((target + pixels - 1) / pixels);
+    if (s < 1) s = 1;
+    if (s > n_samples) s = n_samples;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+rt_ctx* rt_create(int32_t device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0"); return nullptr; }
+    int dev = device_id;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= n) { g_create_error = "device id out of range"; return nullptr; }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) { g_create_error = hipGetErrorString(e); return nullptr; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) { g_create_error = std::string("device is ") + prop.gcnArchName + ", library is built for gfx950 only"; return nullptr; }
+    if ((e = hipSetDevice(dev)) != hipSuccess) { g_create_error = hipGetErrorString(e); return nullptr; }
+    rt_ctx* c = new rt_ctx();
+    c->device = dev;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
+              hipEventCreate(&c->ev1) == hipSuccess && hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)) == hipSuccess &&
+              hipHostMalloc((void**)&c->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+    if (!ok) { g_create_error = "failed to create stream/events/counters"; rt_destroy(c); return nullptr; }
+    memset(c->h_counters, 0, 4 * sizeof(unsigned long long));
+    return c;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->scene_buf.release(); c->partial.release(); c->accum.release(); c->bgra.release(); c->rgb.release();
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int32_t rt_get_stats(const rt_ctx* c, rt_stats* out) {
+    if (!c || !out) return RT_ERR_BAD_ARG;
+    *out = c->stats;
+    return RT_OK;
+}
+
+int32_t rt_whitted_params_default(int32_t example, rt_whitted_params* out) {
+    if (!out || (example != 1 && example != 2)) return RT_ERR_BAD_ARG;
+    out->max_depth = 4; out->shadow_samples = example == 2 ? 16 : 0; out->seed = 1; out->reserved = 0;
+    return RT_OK;
+}
+int32_t rt_path_params_default(int32_t example, rt_path_params* out) {
+    if (!out || (example != 3 && example != 4)) return RT_ERR_BAD_ARG;
+    out->variant = example; out->spp = example == 3 ? 16 : 32; out->max_depth = example == 3 ? 24 : 6; out->seed = 1;
+    out->sample_begin = 0; out->sample_end = 0; out->t_min = example == 3 ? 0.001f : 0.01f; out->t_max = 1000.0f;
+    return RT_OK;
+}
+
+int32_t rt_sync(rt_ctx* c, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (c->timing_pending) {
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->stats.kernel_ms = ms;
+        c->stats.rays = c->h_counters[0]; c->stats.shadow_rays = c->h_counters[1];
+        c->stats.samples = c->pending_samples;
+        c->timing_pending = false;
+    }
+    return RT_OK;
+}
+
+int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p,
+                                  int32_t width, int32_t height, float* d_accum, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!cam || !p || !d_accum || width <= 0 || height <= 0) return fail(c, RT_ERR_BAD_ARG, "rt_path_accumulate_device: null pointer or non-positive size");
+    if ((long long)width * height > (1LL << 28)) return fail(c, RT_ERR_TOO_LARGE, "image larger than 2^28 pixels");
+    if (p->variant != RT_PATH_SKY && p->variant != RT_PATH_LIGHTS) return fail(c, RT_ERR_BAD_ARG, "variant must be 3 or 4");
+    int s0 = p->sample_begin, s1 = p->sample_end;
+    if (s0 == 0 && s1 == 0) s1 = p->spp;
+    if (p->spp <= 0 || s0 < 0 || s1 < s0 || p->max_depth < 0) return fail(c, RT_ERR_BAD_ARG, "bad spp / sample range / max_depth");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    HostScene H; DevScene D;
+    if ((rc = compile_scene(c, scene, p->variant, H))) return rc;
+    if ((rc = upload_scene(c, H, st, D))) return rc;
+
+    PathArgs A{};
+    A.width = width; A.height = height; A.sample_begin = s0; A.sample_end = s1; A.max_depth = p->max_depth;
+    A.jitter = p->spp > 1; A.seed = p->seed; A.t_min = p->t_min; A.t_max = p->t_max;
+    A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : (p->variant == RT_PATH_LIGHTS ? 16 : 8);
+    float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 03 Main.cpp:317
+    float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
+    A.inv_w2 = 2.0f / w; A.inv_h2 = 2.0f / h; A.kx = th * w / h; A.ky = th;
+    rotation_mat(cam->orientation_deg, A.r);
+    A.px = cam->position[0]; A.py = cam->position[1]; A.pz = cam->position[2];
+    int n_samples = s1 - s0;
+    int slices = n_samples > 0 ? pick_slices(width, height, n_samples) : 1;
+    A.slice_len = n_samples > 0 ? (n_samples + slices - 1) / slices : 1;
+    slices = n_samples > 0 ? (n_samples + A.slice_len - 1) / A.slice_len : 1;
+    size_t npx = (size_t)width * height;
+    float4* target = (float4*)d_accum;
+    if (slices > 1) { HIPCHK(c, c->partial.reserve(npx * slices * sizeof(float4))); target = (float4*)c->partial.p; }
+    if ((rc = begin_timed(c, st))) return rc;
+    launch_path(p->variant, D, A, target, slices, c->d_counters, st);
+    HIPCHK(c, hipGetLastError());
+    if (slices > 1) { launch_sum_slices((const float4*)c->partial.p, (int)npx, slices, (float4*)d_accum, st); HIPCHK(c, hipGetLastError()); }
+    c->pending_samples = (uint64_t)npx * (uint64_t)n_samples;
+    return end_timed(c, st);
+}
+
+int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_whitted_params* p,
+                          int32_t width, int32_t height, float* d_color, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!cam || !p || !d_color || width <= 0 || height <= 0) return fail(c, RT_ERR_BAD_ARG, "rt_whitted_device: null pointer or non-positive size");
+    if ((long long)width * height > (1LL << 28)) return fail(c, RT_ERR_TOO_LARGE, "image larger than 2^28 pixels");
+    if (p->max_depth < 0 || p->max_depth > RT_WHITTED_MAX_DEPTH_LIMIT) return fail(c, RT_ERR_TOO_LARGE, "max_depth outside [0, RT_WHITTED_MAX_DEPTH_LIMIT]");
+    if (p->shadow_samples < 0 || p->shadow_samples > RT_MAX_SHADOW_SAMPLES) return fail(c, RT_ERR_TOO_LARGE, "shadow_samples outside [0, RT_MAX_SHADOW_SAMPLES]");
+    for (int k = 0; k < 3; ++k)
+        if (cam->position[k] != 0.0f || cam->orientation_deg[k] != 0.0f) return fail(c, RT_ERR_BAD_ARG, "examples 01/02 have a fixed camera: position/orientation must be zero");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    HostScene H; DevScene D;
+    if ((rc = compile_scene(c, scene, 0, H))) return rc;
+    if ((rc = upload_scene(c, H, st, D))) return rc;
+    WhittedArgs A{};
+    A.width = width; A.height = height; A.max_depth = p->max_depth; A.shadow_samples = p->shadow_samples; A.seed = p->seed;
+    float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 01 Main.cpp:333
+    float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
+    A.inv_w2 = 2.0f / w; A.inv_h2 = 2.0f / h; A.kx = th * w / h; A.ky = th;
+    if ((rc = begin_timed(c, st))) return rc;
+    launch_whitted(p->shadow_samples > 0, D, A, (float4*)d_color, c->d_counters, st);
+    HIPCHK(c, hipGetLastError());
+    c->pending_samples = (uint64_t)width * height;
+    return end_timed(c, st);
+}
+
+int32_t rt_resolve_device(rt_ctx* c, const float* d_accum, int32_t width, int32_t height, float divisor, int32_t gamma,
+                          uint8_t* d_bgra, int32_t stride, float* d_rgb, void* stream) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!d_accum || width <= 0 || height <= 0 || (!d_bgra && !d_rgb)) return fail(c, RT_ERR_BAD_ARG, "rt_resolve_device: null pointer or non-positive size");
+    if (stride == 0) stride = width * 4;
+    if (stride < width * 4 || (stride & 3)) return fail(c, RT_ERR_BAD_ARG, "bgra stride must be >= width*4 and a multiple of 4");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    launch_resolve((const float4*)d_accum, width, height, divisor, gamma, d_bgra, stride, d_rgb, st);
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+static int32_t render_host(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_whitted_params* wp, const rt_path_params* pp, const rt_image* out) {
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!out || out->width <= 0 || out->height <= 0 || (!out->bgra && !out->rgb)) return fail(c, RT_ERR_BAD_ARG, "image: null or non-positive size");
+    int W = out->width, Hh = out->height;
+    size_t npx = (size_t)W * Hh;
+    int stride = out->bgra_stride_bytes ? out->bgra_stride_bytes : W * 4;
+    if (stride < W * 4 || (stride & 3)) return fail(c, RT_ERR_BAD_ARG, "bgra stride must be >= width*4 and a multiple of 4");
+    HIPCHK(c, c->accum.reserve(npx * sizeof(float4)));
+    if (out->bgra) HIPCHK(c, c->bgra.reserve((size_t)stride * Hh));
+    if (out->rgb) HIPCHK(c, c->rgb.reserve(npx * 3 * sizeof(float)));
+    float divisor = 1.0f; int gamma = 0;
+    if (wp) rc = rt_whitted_device(c, scene, cam, wp, W, Hh, (float*)c->accum.p, nullptr);
+    else { rc = rt_path_accumulate_device(c, scene, cam, pp, W, Hh, (float*)c->accum.p, nullptr); divisor = pp ? (float)pp->spp : 1.0f; gamma = 1; }
+    if (rc) return rc;
+    rc = rt_resolve_device(c, (const float*)c->accum.p, W, Hh, divisor, gamma, out->bgra ? (uint8_t*)c->bgra.p : nullptr, stride,
+                           out->rgb ? (float*)c->rgb.p : nullptr, nullptr);
+    if (rc) return rc;
+    if (out->bgra) HIPCHK(c, hipMemcpyAsync(out->bgra, c->bgra.p, (size_t)stride * Hh, hipMemcpyDeviceToHost, c->stream));
+    if (out->rgb) HIPCHK(c, hipMemcpyAsync(out->rgb, c->rgb.p, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = rt_sync(c, nullptr))) return rc;
+    c->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int32_t rt_render_whitted(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_whitted_params* p, const rt_image* out) {
+    if (!c) return RT_ERR_BAD_ARG;
+    if (!p) return fail(c, RT_ERR_BAD_ARG, "params is null");
+    return render_host(c, scene, cam, p, nullptr, out);
+}
+int32_t rt_render_path(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p, const rt_image* out) {
+    if (!c) return RT_ERR_BAD_ARG;
+    if (!p) return fail(c, RT_ERR_BAD_ARG, "params is null");
+    return render_host(c, scene, cam, nullptr, p, out);
+}
+
+// test/bench hook: regeneration threshold (idle lanes per wave); <0 restores the default. Not part of rt_mi355.h.
+int32_t rt_debug_set_regen_threshold(rt_ctx* c, int32_t n) { if (!c) return RT_ERR_BAD_ARG; c->regen_threshold_override = n; return RT_OK; }
+
+} // extern "C"

@@ -1,0 +1,34 @@
+// rt_kernels.h - launch interface between the host side (rt_api.hip) and the kernels (rt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rt_mi355.h"
+
+namespace rt {
+struct DevScene;
+
+struct PathArgs {
+    int width, height;
+    int sample_begin, sample_end;   // samples [begin,end) of every pixel
+    int slice_len;                  // samples per blockIdx.y slice
+    int max_depth;
+    int jitter;                     // spp > 1 (03 Main.cpp:331)
+    int regen_threshold;            // idle lanes per wave that trigger a regeneration pass
+    uint32_t seed;
+    float t_min, t_max;
+    float inv_w2, inv_h2, kx, ky;   // 2/w, 2/h, tan(fov/2)*w/h, tan(fov/2)
+    float r[9];                     // GetRotationMat(orientation), row-major
+    float px, py, pz;
+};
+
+struct WhittedArgs {
+    int width, height, max_depth, shadow_samples;
+    uint32_t seed;
+    float inv_w2, inv_h2, kx, ky;
+};
+
+void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st);
+void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* out, hipStream_t st);
+void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st);
+void launch_resolve(const float4* accum, int width, int height, float divisor, int gamma, uint8_t* bgra, int stride, float* rgb, hipStream_t st);
+} // namespace rt

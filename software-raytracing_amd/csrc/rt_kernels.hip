@@ -1,0 +1,317 @@
+// rt_kernels.hip - the tracing kernels (gfx950).  One thread per pixel(-sample slice); scene
+// primitives are wave-uniform and come through scalar loads; no MFMA (FP32 VALU-bound path).
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+namespace rt {
+
+// =================================================================================================
+// K3/K4: path tracing.  Render + TraceTay of 03 (Main.cpp:310-435) and 04 (Main.cpp:324-502).
+// The recursion out = att * child (+ emitted) is a product chain, so it runs as a loop carrying
+// the throughput; a lane whose path ended takes the next sample of its pixel (regeneration),
+// and a wave regenerates only when enough of its lanes are idle (ballot), so lanes stay busy
+// without paying the camera code on every iteration.
+// =================================================================================================
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_path(DevScene S, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    int px, py;
+    bool inside = pixel_of_thread(A.width, A.height, px, py);
+    const int slice = blockIdx.y;
+    int s_next = A.sample_begin + slice * A.slice_len;
+    int s_end = min(s_next + A.slice_len, A.sample_end);
+    if (!inside) s_next = s_end;
+    const uint32_t pixel = (uint32_t)(py * A.width + px);
+    const uint32_t pkey = rng_pixel_key(A.seed, pixel);
+
+    f3 o = F3(0, 0, 0), d = F3(0, 0, -1), thr = F3(0, 0, 0), acc = F3(0, 0, 0);
+    uint32_t skey = 0;
+    int depth = 0;
+    bool alive = false;
+    unsigned int rays = 0;
+    int n_started = 0;
+
+    for (;;) {
+        bool want = !alive && s_next < s_end;
+        unsigned long long m_want = __ballot(want), m_alive = __ballot(alive);
+        if ((m_want | m_alive) == 0ULL) break;
+        if (m_want && (m_alive == 0ULL || __popcll(m_want) >= A.regen_threshold)) {
+            if (want) {   // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369)
+                skey = rng_sample_key(pkey, (uint32_t)s_next);
+                float bx = 0.5f, by = 0.5f;
+                if (A.jitter) { bx = rng_u01(skey, 0); by = rng_u01(skey, 1); }
+                float x = fmaf((float)px + bx, A.inv_w2, -1.0f) * A.kx;
+                float y = -fmaf((float)py + by, A.inv_h2, -1.0f) * A.ky;
+                f3 v = F3(x, y, -1.0f);
+                d = normalize(F3(dot(F3(A.r[0], A.r[1], A.r[2]), v), dot(F3(A.r[3], A.r[4], A.r[5]), v), dot(F3(A.r[6], A.r[7], A.r[8]), v)));
+                o = F3(A.px, A.py, A.pz);
+                thr = F3(1, 1, 1);
+                depth = 0;
+                alive = true;
+                ++s_next; ++n_started;
+            }
+        }
+        if (alive) {
+            // TraceTay: one scene query (03 Main.cpp:392, 04 Main.cpp:447)
+            ++rays;
+            float t;
+            int idx = closest_hit_shrinking(S, o, d, A.t_min, A.t_max, t);
+            if (idx < 0) {
+                if (VARIANT == 3) {   // sky: Mix(white, (0.5,0.7,1), 0.5*(d.y+1)) (03 Main.cpp:430-432)
+                    float h = 0.5f * (d.y + 1.0f);
+                    acc = acc + thr * F3(fmaf(-0.5f, h, 1.0f), fmaf(-0.3f, h, 1.0f), 1.0f);
+                }
+                alive = false;
+            } else {
+                int4 inf = S.info[idx];
+                f3 p = madd(d, t, o);
+                f3 n;
+                bool back;
+                if (inf.x == PRIM_SPHERE) {          // 03 Sphere.hpp:57-73, 04 Scene/Sphere.hpp:58-74
+                    n = normalize(p - F3(S.geom[inf.y]));
+                    if (inf.w & 1) n = -n;
+                    back = dot(d, n) > 0.0f;
+                } else if (inf.x == PRIM_RECT) {     // 04 Scene/Rectangle.hpp:79-92
+                    float4 r2 = S.geom[inf.y + 2], r3 = S.geom[inf.y + 3], r4 = S.geom[inf.y + 4];
+                    n = F3(r3.z, r3.w, r4.x);
+                    back = dot(F3(r2), d) > 0.0f;
+                } else {                             // plane 04 Scene/Plane.hpp:55-66; triangle likewise
+                    n = F3(S.geom[inf.y]);
+                    back = dot(d, n) > 0.0f;
+                }
+                if (back) n = -n;
+                float4 m0 = S.mats[inf.z * 3], m2 = S.mats[inf.z * 3 + 2];
+                int mtype = __float_as_int(m0.w);
+                if (mtype == MAT_DIFFUSE || mtype == MAT_METAL) {
+                    f3 axis = (mtype == MAT_METAL) ? reflect(d, n) : n;
+                    f3 nd = axis;
+                    if (m2.y >= 0.0f) {
+                        // RndHemisphereVec (03 Utils.h:64-88) / RndHemisphereVec3 (04 Utils.h:132-157)
+                        uint32_t c0 = 4U * ((uint32_t)depth + 1U);
+                        float u_fi = rng_u01(skey, c0), u_th = rng_u01(skey, c0 + 1U);
+                        f3 b = cross(axis, axis + F3(0.01f, 0.01f, 0.01f));
+                        float bl2 = dot(b, b);
+                        bool degenerate = !(bl2 > 0.0f);
+                        b = b * (degenerate ? 0.0f : rsq_fast(bl2));
+                        f3 c = normalize(cross(axis, b));
+                        const float fi_rev = (float)((360.0 / 57.2958f) / 6.283185307179586);   // fi/(2*pi)
+                        float cf = __builtin_amdgcn_cosf(u_fi * fi_rev), sf = __builtin_amdgcn_sinf(u_fi * fi_rev);
+                        float ct, st;
+                        if (VARIANT == 3) {   // theta = U(-1,1)*thetaMax/57.2958
+                            float th_rev = (2.0f * u_th - 1.0f) * m2.y * 0.15915494309189535f;
+                            ct = __builtin_amdgcn_cosf(th_rev); st = __builtin_amdgcn_sinf(th_rev);
+                        } else {              // theta = acos(U(cos(thetaMax/57.2958), 1))
+                            ct = fmaf(1.0f - m2.y, u_th, m2.y);
+                            st = sqrt_fast(fmaxf(fmaf(-ct, ct, 1.0f), 0.0f));
+                        }
+                        f3 ring = madd(c, sf, b * cf);
+                        nd = madd(ring, st, axis * ct);
+                        // Ray's constructor normalises (Common/Ray.hpp:33-34); nd is unit already unless the frame
+                        // collapsed (axis parallel to (1,1,1): Normalize(0) = 0), where it is axis*cos(theta).
+                        if (degenerate) nd = normalize(nd);
+                    }
+                    f3 att = F3(m0);
+                    if (VARIANT == 4) att = att * fmaxf(dot(nd, n), 0.0f);     // 04 Diffuse.hpp:77-78, Metal.hpp:83-84
+                    thr = thr * att;
+                    d = nd; o = p;
+                    ++depth;
+                } else if (mtype == MAT_DIELECTRIC) {   // 03 Materials.hpp:233-265, 04 Refractive.hpp:80-104
+                    float idxr = back ? m0.x : m2.z;   // m0.x = 1/refractionIndex (host-precomputed)
+                    float cosine = fmaxf(-dot(d, n), 0.0f);
+                    float q = 1.0f - cosine, q2 = q * q;
+                    float refl_p = fmaf(1.0f - m2.w, q2 * q2 * q, m2.w);
+                    float u = rng_u01(skey, 4U * ((uint32_t)depth + 1U) + 2U);
+                    f3 nd = (refl_p < u) ? refract(d, n, idxr) : reflect(d, n);
+                    d = nd; o = p;
+                    ++depth;
+                } else {
+                    if (VARIANT == 4 && mtype == MAT_LIGHT && !back) acc = acc + thr * F3(m0);   // Light.hpp:47-54, Main.cpp:480-483
+                    alive = false;
+                }
+                if (depth > A.max_depth) alive = false;   // 03 Main.cpp:383-386, 04 Main.cpp:438-441
+            }
+        }
+    }
+    if (inside) {
+        out[(size_t)slice * A.width * A.height + pixel] = make_float4(acc.x, acc.y, acc.z, (float)n_started);
+    }
+    wave_add_u64(counters + 0, rays);
+}
+
+void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st) {
+    dim3 grid(((A.width + 15) / 16) * ((A.height + 15) / 16), n_slices);
+    if (variant == 3) hipLaunchKernelGGL(k_path<3>, grid, dim3(256), 0, st, S, A, out, counters);
+    else              hipLaunchKernelGGL(k_path<4>, grid, dim3(256), 0, st, S, A, out, counters);
+}
+
+// Sum the per-slice partial images in a fixed order (deterministic), out = float4(sum rgb, samples).
+__global__ __launch_bounds__(256) void k_sum_slices(const float4* __restrict__ part, int n_pixels, int n_slices, float4* __restrict__ out) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 a = part[i];
+    for (int s = 1; s < n_slices; ++s) { float4 b = part[(size_t)s * n_pixels + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    out[i] = a;
+}
+void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum_slices, dim3((n_pixels + 255) / 256), dim3(256), 0, st, part, n_pixels, n_slices, out);
+}
+
+// =================================================================================================
+// K1/K2: Whitted.  Render + TraceTay of 01 (Main.cpp:324-496) and 02 (Main.cpp:341-566).
+// out = Mix(primary, Mix(refl, refr, wr), wp) is linear in the children, so the recursion tree is
+// walked depth-first with a scalar weight per node; the one pending sibling per depth level lives
+// in an LDS slot indexed by depth (bounded by max_depth), never in scratch memory.
+// =================================================================================================
+#define WBLOCK 128
+template <bool SOFT>
+__global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    __shared__ float stk[RT_WHITTED_MAX_DEPTH_LIMIT + 1][8][WBLOCK];   // slot k: o(3) d(3) weight node
+    const int tid = threadIdx.x;
+    // 16x8 pixels per 128-thread block, 8x8 per wave
+    int tiles_x = (A.width + 15) >> 4;
+    int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    int px = tx * 16 + (tid >> 6) * 8 + (tid & 7), py = ty * 8 + ((tid & 63) >> 3);
+    bool inside = px < A.width && py < A.height;
+    const uint32_t pixel = (uint32_t)(py * A.width + px);
+    const uint32_t skey = rng_sample_key(rng_pixel_key(A.seed, pixel), 0U);
+
+    // primary ray (01 Main.cpp:340-344)
+    float x = fmaf((float)px + 0.5f, A.inv_w2, -1.0f) * A.kx;
+    float y = -fmaf((float)py + 0.5f, A.inv_h2, -1.0f) * A.ky;
+    f3 o = F3(0, 0, 0), d = normalize(F3(x, y, -1.0f));
+    float weight = 1.0f, tmin = 0.0f;
+    int depth = 0;
+    uint32_t node = 1U, pending = 0U;
+    f3 acc = F3(0, 0, 0);
+    unsigned int rays = 0, srays = 0;
+    bool active = inside;
+    const f3 sky = F3(0.2f, 0.7f, 0.8f);
+
+    while (__any(active)) {
+        if (active) {
+            bool done_node = true;   // pop after this node unless a child continues in place
+            float t; int idx = -1;
+            if (depth <= A.max_depth) { ++rays; idx = closest_hit_fixed(S, o, d, tmin, 1000.0f, t); }   // :386-403
+            if (idx < 0) {
+                acc = madd(sky, weight, acc);                                                            // :489-493
+            } else {
+                int4 inf = S.info[idx];
+                f3 p = madd(d, t, o);
+                f3 n = (inf.x == PRIM_SPHERE) ? normalize(p - F3(S.geom[inf.y])) : F3(S.geom[inf.y]);   // Sphere.hpp:48, Plane.hpp:48
+                float4 m0 = S.mats[inf.z * 3], m1 = S.mats[inf.z * 3 + 1], m2 = S.mats[inf.z * 3 + 2];
+                float p2s = m1.z, r2r = m1.w;
+                float wp = fmaxf(1.0f - p2s, 0.0f), wr = fmaxf(1.0f - r2r, 0.0f);
+                if (p2s > 0.0f) {                                                                        // :421-447
+                    f3 diffuse = F3(0, 0, 0), specular = F3(0, 0, 0);
+                    for (int li = 0; li < S.n_lights; ++li) {
+                        float4 l0 = S.lights[2 * li], l1 = S.lights[2 * li + 1];
+                        f3 to = F3(l0) - p;
+                        float len2 = dot(to, to);
+                        float len = sqrtf(len2);
+                        f3 tod = to * (len > 0.0f ? 1.0f / len : 0.0f);
+                        float intensity = 1.0f;
+                        if (!SOFT) {                                                                     // 01 :435-436
+                            if (depth + 1 <= A.max_depth) { ++srays; if (any_hit(S, p, tod, 0.01f, len)) intensity = 0.0f; }
+                        } else {                                                                         // 02 :452-467, :539-566
+                            if (depth + 1 <= A.max_depth) {
+                                float per = 1.0f / (float)A.shadow_samples;
+                                f3 lp = F3(l0);
+                                for (int i = 0; i < A.shadow_samples; ++i) {
+                                    uint32_t c = ((node * (uint32_t)S.n_lights + (uint32_t)li) * (uint32_t)A.shadow_samples + (uint32_t)i) * 4U;
+                                    f3 vb = F3(fmaf(2.0f, rng_u01(skey, c), -1.0f), fmaf(2.0f, rng_u01(skey, c + 1U), -1.0f), fmaf(2.0f, rng_u01(skey, c + 2U), -1.0f));
+                                    float rb = rng_u01(skey, c + 3U);
+                                    f3 pl = normalize(cross(tod, tod + vb));
+                                    f3 target = madd(pl, l0.w * rb, lp);
+                                    f3 sd = normalize(target - p);
+                                    ++srays;
+                                    if (any_hit(S, p, sd, 0.01f, len - l0.w)) intensity -= per;
+                                }
+                            }
+                        }
+                        float dd = fmaxf(0.0f, dot(tod, n));
+                        float sdot = fmaxf(0.0f, dot(reflect(-tod, n), -d));
+                        float sp = powf(sdot, m1.y);
+                        if (!SOFT && intensity == 0.0f) continue;   // 01: an occluded light is skipped entirely
+                        diffuse = madd(F3(l1), dd * intensity, diffuse);
+                        specular = madd(F3(l1), sp * intensity, specular);
+                    }
+                    f3 primary = diffuse * F3(m0) + specular * m1.x;                                     // :446
+                    acc = madd(primary, weight * (1.0f - wp), acc);
+                }
+                if (p2s < 1.0f) {                                                                        // :450-481
+                    bool do_refl = r2r > 0.0f, do_refr = r2r < 1.0f;
+                    float w_refl = weight * wp * (1.0f - wr), w_refr = weight * wp * wr;
+                    f3 d_refl = reflect(d, n), d_refr = d;
+                    if (do_refr) {                                                                       // :467-475
+                        float eta = m2.x;
+                        f3 nn = n;
+                        if (dot(n, d) > 0.0f) { nn = -n; eta = 1.0f / eta; }
+                        d_refr = refract(d, nn, eta);
+                    }
+                    int cd = depth + 1;
+                    if (do_refl && do_refr) {   // park the refraction child in the slot of its depth
+                        stk[cd][0][tid] = p.x; stk[cd][1][tid] = p.y; stk[cd][2][tid] = p.z;
+                        stk[cd][3][tid] = d_refr.x; stk[cd][4][tid] = d_refr.y; stk[cd][5][tid] = d_refr.z;
+                        stk[cd][6][tid] = w_refr; stk[cd][7][tid] = __uint_as_float(node * 2U + 1U);
+                        pending |= 1U << cd;
+                    }
+                    if (do_refl || do_refr) {
+                        o = p; tmin = 0.001f; depth = cd;
+                        if (do_refl) { d = normalize(d_refl); weight = w_refl; node = node * 2U; }
+                        else         { d = normalize(d_refr); weight = w_refr; node = node * 2U + 1U; }
+                        done_node = false;
+                    }
+                }
+            }
+            if (done_node) {
+                if (pending == 0U) active = false;
+                else {
+                    int k = 31 - __clz((int)pending);
+                    pending &= ~(1U << k);
+                    o = F3(stk[k][0][tid], stk[k][1][tid], stk[k][2][tid]);
+                    d = normalize(F3(stk[k][3][tid], stk[k][4][tid], stk[k][5][tid]));
+                    weight = stk[k][6][tid]; node = __float_as_uint(stk[k][7][tid]);
+                    depth = k; tmin = 0.001f;
+                }
+            }
+        }
+    }
+    if (inside) out[pixel] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+    wave_add_u64(counters + 0, rays);
+    wave_add_u64(counters + 1, srays);
+}
+
+void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st) {
+    dim3 grid(((A.width + 15) / 16) * ((A.height + 7) / 8));
+    if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), 0, st, S, A, out, counters);
+    else      hipLaunchKernelGGL(k_whitted<false>, grid, dim3(WBLOCK), 0, st, S, A, out, counters);
+}
+
+// =================================================================================================
+// K5: the tail of Render (03 Main.cpp:352-367; 01 Main.cpp:351-356 with gamma off, divisor 1):
+// c = sum/divisor; gamma ? sqrt(c); Clamp(c,0,1)*255 truncated; bytes B,G,R,255.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_resolve(const float4* __restrict__ accum, int width, int height, float divisor, int gamma,
+                                                 uint8_t* __restrict__ bgra, int stride, float* __restrict__ rgb) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= width * height) return;
+    float4 a = accum[i];
+    float c[3] = {a.x / divisor, a.y / divisor, a.z / divisor};
+    if (rgb) { rgb[3 * (size_t)i] = c[0]; rgb[3 * (size_t)i + 1] = c[1]; rgb[3 * (size_t)i + 2] = c[2]; }
+    if (bgra) {
+        unsigned int q[3];
+        for (int k = 0; k < 3; ++k) {
+            float v = gamma ? sqrtf(c[k]) : c[k];
+            v = (v < 0.0f) ? 0.0f : (1.0f < v) ? 1.0f : v;      // math::Clamp (Common/Math.hpp:1119-1122)
+            v = v * 255.0f;
+            q[k] = (v >= 0.0f) ? (unsigned int)v : 0U;          // static_cast<BYTE>: truncation
+        }
+        int yy = i / width, xx = i - yy * width;
+        uchar4 pix = make_uchar4((unsigned char)q[2], (unsigned char)q[1], (unsigned char)q[0], 255);
+        *reinterpret_cast<uchar4*>(bgra + (size_t)yy * stride + 4 * (size_t)xx) = pix;
+    }
+}
+void launch_resolve(const float4* accum, int width, int height, float divisor, int gamma, uint8_t* bgra, int stride, float* rgb, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve, dim3((width * height + 255) / 256), dim3(256), 0, st, accum, width, height, divisor, gamma, bgra, stride, rgb);
+}
+
+} // namespace rt

@@ -1,0 +1,116 @@
+"""ctypes binding of librt_mi355.so (the product).  Mirrors include/rt_mi355.h one to one; there is
+no CPU fallback: a missing library or a missing gfx950 device raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+LIB_PATH = os.path.join(_HERE, "librt_mi355.so")
+_LIB = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt_mi355 error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C software-raytracing_amd` "
+                               "(or __graft_entry__.build()); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER
+        L.rt_create.restype = C.c_void_p
+        L.rt_create.argtypes = [C.c_int32]
+        L.rt_destroy.argtypes = [C.c_void_p]
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_last_error.argtypes = [C.c_void_p]
+        L.rt_get_stats.argtypes = [C.c_void_p, P(abi.rt_stats)]
+        L.rt_whitted_params_default.argtypes = [C.c_int32, P(abi.rt_whitted_params)]
+        L.rt_path_params_default.argtypes = [C.c_int32, P(abi.rt_path_params)]
+        L.rt_render_whitted.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_whitted_params), P(abi.rt_image)]
+        L.rt_render_path.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_path_params), P(abi.rt_image)]
+        L.rt_path_accumulate_device.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_path_params),
+                                                C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.rt_whitted_device.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_whitted_params),
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.rt_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_debug_set_regen_threshold.argtypes = [C.c_void_p, C.c_int32]
+        _LIB = L
+    return _LIB
+
+
+class Context:
+    """rt_ctx owner.  One per process/device (the four Render wrappers share one)."""
+
+    def __init__(self, device_id=-1):
+        self.L = load()
+        self.h = self.L.rt_create(device_id)
+        if not self.h:
+            raise RtError(abi.RT_ERR_NO_DEVICE, self.L.rt_last_error(None).decode())
+
+    def close(self):
+        if self.h:
+            self.L.rt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RtError(rc, self.L.rt_last_error(self.h).decode())
+
+    def stats(self):
+        st = abi.rt_stats()
+        self._chk(self.L.rt_get_stats(self.h, C.byref(st)))
+        return dict(rays=st.rays, shadow_rays=st.shadow_rays, samples=st.samples, kernel_ms=st.kernel_ms, total_ms=st.total_ms)
+
+    # ---- host-buffer entry points ---------------------------------------------------------
+    def _image(self, width, height, want_rgb=True):
+        bgra = np.zeros((height, width, 4), np.uint8)
+        rgb = np.zeros((height, width, 3), np.float32) if want_rgb else None
+        img = abi.rt_image(bgra.ctypes.data, rgb.ctypes.data if want_rgb else None, width, height, 0)
+        return img, bgra, rgb
+
+    def render_whitted(self, scene, cam, prm, width, height):
+        img, bgra, rgb = self._image(width, height)
+        sc = scene.c()
+        self._chk(self.L.rt_render_whitted(self.h, C.byref(sc), C.byref(cam), C.byref(prm), C.byref(img)))
+        return dict(bgra=bgra, rgb=rgb, **self.stats())
+
+    def render_path(self, scene, cam, prm, width, height):
+        img, bgra, rgb = self._image(width, height)
+        sc = scene.c()
+        self._chk(self.L.rt_render_path(self.h, C.byref(sc), C.byref(cam), C.byref(prm), C.byref(img)))
+        return dict(bgra=bgra, rgb=rgb, **self.stats())
+
+    # ---- device-buffer entry points (raw device pointers, e.g. torch tensor .data_ptr()) -----
+    def path_accumulate_device(self, scene, cam, prm, width, height, d_accum_ptr, stream=None):
+        sc = scene.c()
+        self._chk(self.L.rt_path_accumulate_device(self.h, C.byref(sc), C.byref(cam), C.byref(prm), width, height, d_accum_ptr, stream))
+
+    def whitted_device(self, scene, cam, prm, width, height, d_color_ptr, stream=None):
+        sc = scene.c()
+        self._chk(self.L.rt_whitted_device(self.h, C.byref(sc), C.byref(cam), C.byref(prm), width, height, d_color_ptr, stream))
+
+    def resolve_device(self, d_accum_ptr, width, height, divisor, gamma, d_bgra_ptr, stride=0, d_rgb_ptr=None, stream=None):
+        self._chk(self.L.rt_resolve_device(self.h, d_accum_ptr, width, height, divisor, int(gamma), d_bgra_ptr, stride, d_rgb_ptr, stream))
+
+    def sync(self, stream=None):
+        self._chk(self.L.rt_sync(self.h, stream))
+        return self.stats()
+
+    def set_regen_threshold(self, n):
+        self._chk(self.L.rt_debug_set_regen_threshold(self.h, n))

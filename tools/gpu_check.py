@@ -1,0 +1,64 @@
+"""Exploratory GPU-vs-oracle comparison (prints metrics; the pass/fail versions live in tests/)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
+from rtamd import abi, lib, oracle, scenes  # noqa: E402
+
+
+def cmp_rgb(name, g, o, tol=1e-4):
+    d = np.abs(g - o)
+    rel = d / np.maximum(np.abs(o), 1e-3)
+    bad = (rel > tol).any(axis=-1)
+    print(f"  {name}: max abs {d.max():.3e}  frac px rel>{tol:g}: {bad.mean():.5f}  mean abs {d.mean():.3e}", flush=True)
+
+
+def main():
+    ctx = lib.Context()
+    W, H = 784, 561
+    # 01
+    s, cam, prm = scenes.scene01()
+    g = ctx.render_whitted(s, cam, prm, W, H)
+    o = oracle.render_whitted(s, cam, prm, W, H, threads=8)
+    print(f"01: gpu rays {g['rays']} shadow {g['shadow_rays']} kernel {g['kernel_ms']:.3f} ms | oracle rays {o['rays']} shadow {o['shadow_rays']}")
+    cmp_rgb("01 rgb", g["rgb"], o["rgb"])
+    db = np.abs(g["bgra"].astype(int) - o["bgra"].astype(int))
+    print(f"  01 bytes: max diff {db.max()} frac px differing {(db.max(axis=-1) > 0).mean():.6f}")
+    # 02
+    s, cam, prm = scenes.scene02(16, seed=1)
+    g = ctx.render_whitted(s, cam, prm, W, H)
+    o = oracle.render_whitted(s, cam, prm, W, H, threads=8)
+    print(f"02: gpu rays {g['rays']} shadow {g['shadow_rays']} kernel {g['kernel_ms']:.3f} ms | oracle rays {o['rays']} shadow {o['shadow_rays']}")
+    cmp_rgb("02 rgb", g["rgb"], o["rgb"])
+    # 03 / 04 small
+    for name, (s, cam, prm), (w, h) in [("03", scenes.scene03(16), (196, 140)), ("04", scenes.scene04(32), (196, 140))]:
+        g = ctx.render_path(s, cam, prm, w, h)
+        o = oracle.render_path(s, cam, prm, w, h, threads=8)
+        om = o["sum"] / prm.spp
+        print(f"{name}: gpu rays {g['rays']} samples {g['samples']} kernel {g['kernel_ms']:.3f} ms | oracle rays {o['rays']}")
+        cmp_rgb(f"{name} mean rgb", g["rgb"], om, 1e-3)
+        print(f"  {name} image mean gpu {g['rgb'].mean(axis=(0, 1))} oracle {om.mean(axis=(0, 1))}")
+    # throughput probes
+    for name, (s, cam, prm), (w, h) in [("03", scenes.scene03(256), (1920, 1080)), ("04", scenes.scene04(64), (3840, 2160)),
+                                         ("04", scenes.scene04(32), (784, 561))]:
+        for thr in ([1, 8, 16, 32, 64] if (w, h) != (784, 561) else [16]):
+            ctx.set_regen_threshold(thr)
+            t0 = time.time()
+            g = ctx.render_path(s, cam, prm, w, h)
+            dt = time.time() - t0
+            print(f"{name} {w}x{h} spp {prm.spp} regen {thr}: kernel {g['kernel_ms']:.2f} ms total {dt*1e3:.1f} ms rays {g['rays']} "
+                  f"({g['rays']/g['samples']:.3f}/sample) -> {g['rays']/g['kernel_ms']/1e6:.2f} Grays/s", flush=True)
+        ctx.set_regen_threshold(-1)
+    for ss in [1, 16, 256]:
+        s, cam, prm = scenes.scene02(ss)
+        g = ctx.render_whitted(s, cam, prm, 3840, 2160)
+        tot = g["rays"] + g["shadow_rays"]
+        print(f"02 4K shadow_samples {ss}: kernel {g['kernel_ms']:.2f} ms rays {tot} -> {tot/g['kernel_ms']/1e6:.2f} Grays/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+// ubench.hip - VALU issue-rate probe for gfx950: how many lane-ops/s the chip sustains for the
+// instructions the tracing kernels are made of.  Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define ITER 4096
+#define CHAINS 8
+
+#define KERNEL(NAME, DECL, BODY)                                                              \
+    __global__ __launch_bounds__(256) void NAME(float* out, float a, float b) {               \
+        DECL;                                                                                 \
+        for (int i = 0; i < ITER; ++i) {                                                      \
+            _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) { BODY; }                      \
+        }                                                                                     \
+        float s = 0;                                                                          \
+        for (int c = 0; c < CHAINS; ++c) s += (float)x[c];                                    \
+        out[blockIdx.x * 256 + threadIdx.x] = s;                                              \
+    }
+
+KERNEL(k_fma, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b)))
+KERNEL(k_mul, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_cndmask, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_cmp, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cmp_lt_f32 vcc, %0, %1" : "+v"(x[c]) : "v"(a) : "vcc"))
+KERNEL(k_sqrt, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c + 1, asm volatile("v_sqrt_f32 %0, %0" : "+v"(x[c])))
+KERNEL(k_rcp, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c + 1, asm volatile("v_rcp_f32 %0, %0" : "+v"(x[c])))
+KERNEL(k_sin, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = 0.001f * (threadIdx.x + c), asm volatile("v_sin_f32 %0, %0" : "+v"(x[c])))
+KERNEL(k_mullo, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_mul24, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_mad24, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
+KERNEL(k_xor, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_lshr, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(x[c])))
+KERNEL(k_cvt, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x[c])))
+
+
+KERNEL(k_cnd64, float x[CHAINS]; unsigned long long m = __ballot(threadIdx.x & 1); for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "s"(m)))
+KERNEL(k_cmpcnd, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(x[c]) : "v"(a), "v"(b) : "vcc"))
+KERNEL(k_min, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_min_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_add, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_fmac, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b)))
+KERNEL(k_fmas, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "s"(a), "v"(b)))
+KERNEL(k_rsq, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c + 1, asm volatile("v_rsq_f32 %0, %0" : "+v"(x[c])))
+KERNEL(k_mov, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mov_b32 %0, %1" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_mulhi, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_xad, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
+KERNEL(k_med3, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b)))
+__global__ __launch_bounds__(256) void k_clock(float* out, float a, float b) {
+    float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < ITER * 4; ++i) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0; for (int c = 0; c < CHAINS; ++c) s += x[c];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 100 && threadIdx.x == 0) printf("in-kernel clock under v_fma load: %.1f MHz (cycles %llu, realtime ticks %llu)\n", 100.0 * (double)(t1 - t0) / (double)(r1 - r0), t1 - t0, r1 - r0);
+}
+
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_pkfma(float* out, float a, float b) {
+    float2_t x[CHAINS], av = {a, a}, bv = {b, b};
+    for (int c = 0; c < CHAINS; ++c) x[c] = (float2_t){(float)threadIdx.x, (float)c};
+    for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(av), "v"(bv));
+    }
+    float s = 0;
+    for (int c = 0; c < CHAINS; ++c) s += x[c].x + x[c].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <typename K>
+void run(const char* name, K k, float* d, double ops_per_instr) {
+    int blocks = 256 * 8;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.5f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.5f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double lane_instr = 5.0 * blocks * 256.0 * ITER * CHAINS;
+    double rate = lane_instr / (ms * 1e-3);
+    printf("%-12s %8.3f ms  %7.2f Tlane-instr/s  (%.1f %s)  cycles/wave-instr/SIMD @2.4GHz: %.2f\n", name, ms, rate / 1e12,
+           rate * ops_per_instr / 1e12, "Tops/s", 256.0 * 4 * 2.4e9 * 64 / rate);
+}
+
+int main() {
+    float* d; hipMalloc(&d, 256 * 8 * 256 * sizeof(float));
+    run("v_fma_f32", k_fma, d, 2); run("v_pk_fma_f32", k_pkfma, d, 4); run("v_mul_f32", k_mul, d, 1);
+    run("v_cndmask", k_cndmask, d, 1); run("v_cmp", k_cmp, d, 1); run("v_sqrt_f32", k_sqrt, d, 1); run("v_rcp_f32", k_rcp, d, 1);
+    run("v_sin_f32", k_sin, d, 1); run("v_mul_lo_u32", k_mullo, d, 1); run("v_mul_u32_u24", k_mul24, d, 1); run("v_mad_u32_u24", k_mad24, d, 1);
+    run("v_xor_b32", k_xor, d, 1); run("v_lshrrev", k_lshr, d, 1); run("v_cvt_f32_u32", k_cvt, d, 1);
+    run("cndmask_e64(sgpr)", k_cnd64, d, 1); run("cmp+cndmask", k_cmpcnd, d, 2); run("v_min_f32", k_min, d, 1); run("v_add_f32", k_add, d, 1);
+    run("v_fmac_f32", k_fmac, d, 2); run("v_fma sgpr", k_fmas, d, 2); run("v_rsq_f32", k_rsq, d, 1); run("v_mov_b32", k_mov, d, 1);
+    run("v_mul_hi_u32", k_mulhi, d, 1); run("v_xad_u32", k_xad, d, 1); run("v_med3_f32", k_med3, d, 1);
+    hipLaunchKernelGGL(k_clock, dim3(2048), dim3(256), 0, 0, d, 1.0001f, 0.5f); hipDeviceSynchronize();
+    hipFree(d);
+    return 0;
+}
