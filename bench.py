@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py - rays/s of the 04_PathTracingLights tracing path on MI355X.
+
+A step = one full render of BASELINE.json config 4: the 04 scene at 3840x2160, 1024 spp, depth 6
+(8.49e9 pixel-samples, ~5.8e10 rays), inputs (the flattened scene) resident in HBM, output = the
+8-bit BGRA frame in HBM.  With N ranks (one process per GPU, torch.distributed/RCCL) the frame's
+samples are split into N contiguous ranges - rank r renders samples [r*spp/N, (r+1)*spp/N) of every
+pixel - and the per-GPU float accumulators (3840*2160*4 floats = 132.7 MB) are combined with ONE
+all-reduce over xGMI before the resolve; total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line (rank 0).  roofline: FP32 VALU (no MFMA on this path), algorithmic FLOPs per ray
+from SURVEY.md 8(d) (04 scene: 249) x rays the kernel counted / the kernel's HIP-event duration.
+cpu_baseline: the CPU oracle (a restatement, kind "port") on a band of rows of the same frame."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
+
+PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (vector)"
+
+
+def cpu_baseline(scenes, width, height, spp, rows, threads):
+    """Times the oracle on `rows` rows in the middle of the same frame (same scene, camera, spp)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from rtamd import oracle
+    s, cam, prm = scenes.scene04(spp, seed=1)
+    L = oracle.lib()
+    sc = s.c()
+    y0 = height // 2 - rows // 2
+    counts = []
+
+    def band(y):
+        cnt = (C.c_uint64 * 2)(0, 0)
+        rc = L.orc_render_path(C.byref(sc), C.byref(cam), C.byref(prm), width, height, y, y + 1, None, None, None, cnt)
+        assert rc == 0
+        counts.append(cnt[0])
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(band, range(y0, y0 + rows)))
+    dt = time.perf_counter() - t0
+    rays = int(sum(counts))
+    return {"value": rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/rt_oracle.c (CPU restatement, gcc -O2) on rows {y0}..{y0 + rows - 1} of the same {width}x{height} frame at {spp} spp: "
+                      f"{rays} rays in {dt:.1f} s on {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rtamd import abi, lib, scenes, shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path to time")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    W, H, SPP = args.width, args.height, args.spp
+    ctx = lib.Context(local)
+    s, cam, _ = scenes.scene04(SPP, seed=1)
+    s_begin, s_end = shard.sample_range(rank, world, SPP)
+    prm = scenes.path_params(abi.RT_PATH_LIGHTS, SPP, seed=1, sample_begin=s_begin, sample_end=s_end)
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+    accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
+    bgra = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+
+    def step():
+        ctx.path_accumulate_device(s, cam, prm, W, H, accum.data_ptr(), sp)
+        if world > 1:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM)          # the one collective: per-GPU spp accumulators
+        ctx.resolve_device(accum.data_ptr(), W, H, float(SPP), 1, bgra.data_ptr(), 0, None, sp)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms, rays = [], 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = ctx.sync(sp)          # waits for this step (also collects the kernel's ray counter and HIP-event time)
+        kernel_ms.append(st["kernel_ms"]); rays = st["rays"]
+    fence()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    r = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    dt = float(t.item()); rays_step = float(r.item())
+
+    if rank == 0:
+        fpr = scenes.flops_per_ray(s, 100)                           # 17*3 + 12*5 + 38 + 100 = 249
+        k_ms = float(np.mean(kernel_ms))                             # rank 0's tracing kernel (+slice sum), HIP events on its stream
+        achieved = rays * fpr / (k_ms * 1e-3) / 1e12
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if world == 1 and os.path.exists(pj):
+            try:
+                pm = json.load(open(pj))
+                if pm.get("workload") == f"{W}x{H}x{SPP}":
+                    traffic = pm.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "rays/sec (whole node) on 04 path-tracing scene, 1/2/4/8 GPUs; % FP32 VALU peak",
+            "value": rays_step * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"04_PathTracingLights scene (5 planes, 3 spheres, 1 emissive rectangle), {W}x{H}, {SPP} spp, max depth 6, seed 1",
+                       "samples_per_step": W * H * SPP, "rays_per_step": rays_step, "samples_per_sec": W * H * SPP * args.steps / dt,
+                       "parallelism": f"sample-range x{world}, one all-reduce(sum) of the {W * H * 16 / 1e6:.1f} MB accumulator" if world > 1 else "single GPU"},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": traffic, "kernel": "rt::k_path<4>", "kernel_ms": k_ms, "flops_per_ray": fpr, "rays_per_launch": rays,
+                         "note": "FP32 VALU-bound path (no MFMA, negligible HBM traffic): algorithmic FLOPs/ray x rays / kernel time vs the FP32 vector peak"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(scenes, W, H, SPP, args.cpu_rows, threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

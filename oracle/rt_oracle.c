@@ -611,11 +611,12 @@ int orc_render_path(const rt_scene* scene, const rt_camera* cam, const rt_path_p
     return RT_OK;
 }
 
-/* The tail of Render on an already averaged linear image (used to check rt_resolve_device). */
-void orc_resolve(const float* rgb, int n_pixels, float scale, int gamma, uint8_t* bgra) {
+/* The tail of Render (03 Main.cpp:352-367): sum/divisor, optional sqrt gamma, Clamp, truncation, B,G,R,255
+ * (used to check rt_resolve_device). */
+void orc_resolve(const float* rgb, int n_pixels, float divisor, int gamma, uint8_t* bgra) {
     for (int p = 0; p < n_pixels; p++) {
         float c[3];
-        for (int k = 0; k < 3; k++) { c[k] = rgb[p * 3 + k] * scale; if (gamma) c[k] = sqrtf(c[k]); }
+        for (int k = 0; k < 3; k++) { c[k] = rgb[p * 3 + k] / divisor; if (gamma) c[k] = sqrtf(c[k]); }
         bgra[p * 4 + 0] = quant(c[2]); bgra[p * 4 + 1] = quant(c[1]); bgra[p * 4 + 2] = quant(c[0]); bgra[p * 4 + 3] = 255;
     }
 }
@@ -694,4 +695,15 @@ void orc_scatter_explicit(int variant, const rt_material* m, const float* in_d, 
     }
     out_dir[0] = r.d.x; out_dir[1] = r.d.y; out_dir[2] = r.d.z;
     out_att[0] = att.x; out_att[1] = att.y; out_att[2] = att.z;
+}
+void orc_mix(const float* a, const float* b, float r, float* out) { v3 m = mix3(pv(a), pv(b), r); out[0] = m.x; out[1] = m.y; out[2] = m.z; }
+float orc_clamp(float v, float lo, float hi) { return clampf(v, lo, hi); }
+void orc_ray_ctor(const float* d, float* out) { ray_t r = make_ray(V(0, 0, 0), pv(d)); out[0] = r.d.x; out[1] = r.d.y; out[2] = r.d.z; }
+/* One prim query in Whitted (01/02) form: t and the raw normal. */
+int orc_prim_hit_whitted(const rt_prim* p, const float* o, const float* d, float tmin, float tmax, float* t, float* n) {
+    ray_t ray; ray.o = pv(o); ray.d = pv(d);
+    v3 nn = V(0, 0, 0);
+    int r = prim_hit_whitted(p, &ray, tmin, tmax, t, &nn);
+    if (r) { n[0] = nn.x; n[1] = nn.y; n[2] = nn.z; }
+    return r;
 }

@@ -84,10 +84,10 @@ def render_path(scene, cam, prm, width, height, threads=1, want_sumsq=False):
     return dict(sum=s, sumsq=s2, bgra=bgra, rays=sum(totals))
 
 
-def resolve(rgb, scale, gamma):
+def resolve(rgb, divisor, gamma):
     L = lib()
     rgb = np.ascontiguousarray(rgb, np.float32)
     n = rgb.size // 3
     out = np.zeros((n, 4), np.uint8)
-    L.orc_resolve(_fp(rgb), n, scale, int(gamma), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    L.orc_resolve(_fp(rgb), n, divisor, int(gamma), out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out.reshape(rgb.shape[:-1] + (4,))

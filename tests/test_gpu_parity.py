@@ -1,0 +1,285 @@
+"""GPU parity: the HIP path, called through the C ABI (librt_mi355.so via ctypes), against the CPU oracle
+on the same seeded inputs, against the golden fixtures, and - at BASELINE.json's full sizes - through
+size-independent properties.  Tolerances (BASELINE.json north_star):
+  01/02 (deterministic at a fixed seed): per pixel within 1e-4 relative FP32 on >= 99.9 % of the pixels
+        (the rest sit on hit/shadow discontinuities, where a 1-ulp difference flips a decision), bytes +-1 LSB;
+  03/04 (path traced): identical counter-RNG => identical paths except where a 1-ulp difference flips a
+        decision, so per-pixel agreement is a fraction, plus an RMSE bound from the measured sample variance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import frac_within, load_png_rgb
+from rtamd import abi, lib, oracle, scenes
+
+pytestmark = pytest.mark.gpu
+W, H = 784, 561
+
+
+# ---- 01 / 02 ---------------------------------------------------------------------------------------
+def test_01_default_resolution(ctx, recorded):
+    s, cam, prm = scenes.scene01()
+    g = ctx.render_whitted(s, cam, prm, W, H)
+    o = oracle.render_whitted(s, cam, prm, W, H, threads=8)
+    assert (g["rays"], g["shadow_rays"]) == (o["rays"], o["shadow_rays"])
+    assert g["rays"] + g["shadow_rays"] == recorded["survey"]["01_rays_784x561"]
+    assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.999
+    db = np.abs(g["bgra"].astype(int) - o["bgra"].astype(int))
+    assert db.max() <= 1 and (db.max(axis=-1) > 0).mean() < 1e-3
+    # and directly against the reference's own screenshot
+    png = load_png_rgb(recorded["readme"]["01"]["file"]).astype(int)
+    x, y = recorded["readme"]["01"]["crop_xy"]
+    mine = g["bgra"][y:y + png.shape[0], x:x + png.shape[1], 2::-1].astype(int)
+    d = np.abs(mine - png)
+    assert d.max() <= 1 and (d.max(axis=-1) > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("samples", [1, 4, 16, 64])
+def test_02_shadow_sample_sweep(ctx, samples):
+    w, h = (W, H) if samples == 16 else (196, 140)
+    s, cam, prm = scenes.scene02(samples, seed=1)
+    g = ctx.render_whitted(s, cam, prm, w, h)
+    o = oracle.render_whitted(s, cam, prm, w, h, threads=8)
+    assert g["rays"] == o["rays"] == w * h
+    assert g["shadow_rays"] == o["shadow_rays"] == samples * w * h      # exactly 1 + samples rays per pixel
+    assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.998
+    assert abs(g["rgb"].mean() - o["rgb"].mean()) < 1e-4
+
+
+def test_whitted_recursion_tree_both_branches(ctx):
+    """0 < reflectToRefract < 1 spawns reflection AND refraction at every hit (binary tree, depth 5);
+    also covers triangles, a material-less primitive and two lights."""
+    s = scenes.Scene()
+    half = s.phong((0.2, 0.3, 0.4), 0.8, 64.0, 0.5, 0.5, 0.7)
+    matte = s.phong((0.8, 0.8, 0.8), 0.2, 8.0)
+    s.plane(matte, (0, -4, 0), (0, 1, 0)); s.plane(matte, (0, 0, -30), (0, 0, 1))
+    s.sphere(half, (-2.5, -1, -10), 2.5); s.sphere(half, (3, -1.5, -12), 2.0); s.sphere(-1, (0, 3, -14), 1.5)
+    s.triangle(half, (-8, -4, -18), (8, -4, -18), (0, 8, -22))
+    s.light((5, 9, -4), (0.7, 0.7, 0.6)); s.light((-6, 6, -2), (0.3, 0.3, 0.5), 1.0)
+    cam = scenes.camera(70.0)
+    for samples in (0, 3):
+        prm = scenes.whitted_params(4, samples, seed=9)
+        g = ctx.render_whitted(s, cam, prm, 200, 150)
+        o = oracle.render_whitted(s, cam, prm, 200, 150, threads=8)
+        assert (g["rays"], g["shadow_rays"]) == (o["rays"], o["shadow_rays"])
+        assert g["rays"] > 2 * 200 * 150      # the tree really branched
+        assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.995
+    prm = scenes.whitted_params(8, 0)
+    g = ctx.render_whitted(s, cam, prm, 96, 64)
+    o = oracle.render_whitted(s, cam, prm, 96, 64, threads=8)
+    assert (g["rays"], g["shadow_rays"]) == (o["rays"], o["shadow_rays"])
+    assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.99
+
+
+# ---- 03 / 04 ---------------------------------------------------------------------------------------
+def _path_pair(ctx, scene_fn, spp, w, h, **kw):
+    s, cam, prm = scene_fn(spp, **kw)
+    g = ctx.render_path(s, cam, prm, w, h)
+    o = oracle.render_path(s, cam, prm, w, h, threads=8, want_sumsq=True)
+    return g, o, prm
+
+
+def test_04_same_paths_as_oracle(ctx):
+    g, o, prm = _path_pair(ctx, scenes.scene04, 32, 196, 140)
+    om = o["sum"] / prm.spp
+    assert abs(g["rays"] - o["rays"]) <= 1e-4 * o["rays"]
+    assert frac_within(g["rgb"], om, 1e-3) >= 0.995
+    assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=2e-3)
+    db = np.abs(g["bgra"].astype(int) - o["bgra"].astype(int))
+    assert (db.max(axis=-1) <= 1).mean() >= 0.995
+
+
+def test_03_same_paths_as_oracle(ctx):
+    g, o, prm = _path_pair(ctx, scenes.scene03, 16, 196, 140)
+    om = o["sum"] / prm.spp
+    assert abs(g["rays"] - o["rays"]) <= 5e-3 * o["rays"]
+    assert frac_within(g["rgb"], om, 1e-3) >= 0.97      # long specular chains amplify 1-ulp differences
+    assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=2e-3)
+
+
+def test_03_dielectric_and_inverted_sphere(ctx):
+    g, o, prm = _path_pair(ctx, scenes.scene03, 16, 196, 140, readme_variant=True)
+    om = o["sum"] / prm.spp
+    assert abs(g["rays"] - o["rays"]) <= 5e-3 * o["rays"]
+    assert frac_within(g["rgb"], om, 1e-3) >= 0.95
+    assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=3e-3)
+
+
+@pytest.mark.parametrize("scene_fn,n_gpu,n_cpu", [(scenes.scene04, 2048, 256), (scenes.scene03, 1024, 128)])
+def test_converged_image_rmse_bound(ctx, scene_fn, n_gpu, n_cpu):
+    """Independent seeds: RMSE(gpu, oracle) <= 1.1 * sqrt(mean(var) * (1/N_gpu + 1/N_cpu)) and per-channel means within 1 %
+    (SURVEY.md 8(c) bound; the variance is the oracle's per-pixel sample variance)."""
+    w, h = 98, 70
+    s, cam, prm = scene_fn(n_gpu, seed=101)
+    g = ctx.render_path(s, cam, prm, w, h)
+    s2, cam2, prm2 = scene_fn(n_cpu, seed=202)
+    o = oracle.render_path(s2, cam2, prm2, w, h, threads=8, want_sumsq=True)
+    om = o["sum"] / n_cpu
+    var = np.maximum(o["sumsq"] / n_cpu - om ** 2, 0) * n_cpu / (n_cpu - 1)
+    bound = 1.1 * np.sqrt(var.mean() * (1.0 / n_gpu + 1.0 / n_cpu))
+    rmse = np.sqrt(((g["rgb"] - om) ** 2).mean())
+    assert rmse <= bound, (rmse, bound)
+    assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=0.01)
+
+
+def test_path_edge_cases(ctx):
+    s, cam, prm = scenes.scene04(1)                       # spp == 1: pixel centre, no jitter (04 Main.cpp:359)
+    for (w, h) in [(1, 1), (17, 3), (33, 31)]:            # sizes that are not multiples of the 16x16 tile
+        g = ctx.render_path(s, cam, prm, w, h)
+        o = oracle.render_path(s, cam, prm, w, h)
+        assert frac_within(g["rgb"], o["sum"], 1e-3) >= 0.95 and g["samples"] == w * h
+    prm0 = scenes.path_params(abi.RT_PATH_LIGHTS, 4, max_depth=0)   # depth 0: only directly visible emission
+    g = ctx.render_path(s, cam, prm0, 64, 48)
+    o = oracle.render_path(s, cam, prm0, 64, 48)
+    assert g["rays"] == o["rays"] == 64 * 48 * 4
+    assert np.allclose(g["rgb"], o["sum"] / 4, atol=1e-5)
+    empty = scenes.Scene(); empty.diffuse((1, 1, 1))       # no primitives: sky everywhere / black
+    g = ctx.render_path(empty, scenes.camera(50.0), scenes.path_params(abi.RT_PATH_SKY, 2), 32, 16)
+    o = oracle.render_path(empty, scenes.camera(50.0), scenes.path_params(abi.RT_PATH_SKY, 2), 32, 16)
+    assert np.allclose(g["rgb"], o["sum"] / 2, atol=1e-5) and g["rgb"].min() > 0.4
+    g = ctx.render_path(empty, scenes.camera(50.0), scenes.path_params(abi.RT_PATH_LIGHTS, 2), 32, 16)
+    assert g["rgb"].max() == 0.0 and (g["bgra"][:, :, :3] == 0).all() and (g["bgra"][:, :, 3] == 255).all()
+
+
+def test_mixed_primitives_path(ctx):
+    """triangles + flipped sphere + rectangle at a two-axis orientation + material-less primitive, 04 semantics."""
+    s = scenes.Scene()
+    white = s.diffuse((0.7, 0.7, 0.7)); metal = s.metal((0.9, 0.8, 0.7), 0.1); glass = s.dielectric(0.7)
+    lm = s.light_material((8, 7, 6))
+    s.plane(white, (0, -3, 0), (0, 1, 0)); s.plane(white, (0, 0, -12), (0.2, 0.1, 1.0))
+    s.triangle(metal, (-6, -3, -9), (-1, -3, -11), (-4, 3, -10)); s.triangle(white, (6, -3, -9), (4, 3, -10), (1, -3, -11))
+    s.sphere(glass, (0, -1.5, -6), 1.5); s.sphere(glass, (0, -1.5, -6), 1.2, flip=True); s.sphere(-1, (3, -2.5, -5), 0.5)
+    s.rect(lm, (0, 5, -6), (4, 3), (70, 20, 0)); s.rect(lm, (-5, 0, -6), (2, 2), (0, 60, 0))
+    cam = scenes.camera(75.0, (0.5, 0.2, 2.0), (-5, 8, 3))
+    prm = scenes.path_params(abi.RT_PATH_LIGHTS, 16, max_depth=5, seed=4)
+    g = ctx.render_path(s, cam, prm, 160, 120)
+    o = oracle.render_path(s, cam, prm, 160, 120, threads=8)
+    om = o["sum"] / 16
+    assert abs(g["rays"] - o["rays"]) <= 5e-3 * o["rays"]
+    assert frac_within(g["rgb"], om, 1e-3) >= 0.97
+    assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=1e-2)
+
+
+# ---- device-buffer entry points, sharding, resolve -----------------------------------------------------
+def test_sample_range_sharding_is_additive(ctx):
+    import torch
+    w, h, spp = 200, 120, 24
+    s, cam, _ = scenes.scene04(spp)
+    full = torch.empty(h * w * 4, dtype=torch.float32, device="cuda")
+    parts = [torch.empty_like(full) for _ in range(3)]
+    ctx.path_accumulate_device(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, spp, seed=5), w, h, full.data_ptr())
+    st = ctx.sync()
+    rays = 0
+    for k, (a, b) in enumerate([(0, 7), (7, 8), (8, 24)]):     # ragged ranges incl. a single sample
+        ctx.path_accumulate_device(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, spp, seed=5, sample_begin=a, sample_end=b), w, h, parts[k].data_ptr())
+        rays += ctx.sync()["rays"]
+    assert rays == st["rays"]
+    tot = (parts[0] + parts[1] + parts[2]).cpu().numpy().reshape(h, w, 4)
+    f = full.cpu().numpy().reshape(h, w, 4)
+    assert (tot[:, :, 3] == spp).all() and (f[:, :, 3] == spp).all()
+    assert np.allclose(tot[:, :, :3], f[:, :, :3], rtol=1e-5, atol=1e-6)   # only the float summation order differs
+    # empty range: zeros
+    ctx.path_accumulate_device(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, spp, seed=5, sample_begin=5, sample_end=5), w, h, parts[0].data_ptr())
+    ctx.sync()
+    assert float(parts[0].abs().max()) == 0.0
+
+
+def test_resolve_is_bit_exact(ctx):
+    import torch
+    rng = np.random.default_rng(0)
+    w, h = 333, 77
+    acc = np.zeros((h, w, 4), np.float32)
+    acc[:, :, :3] = rng.gamma(0.6, 40.0, (h, w, 3)).astype(np.float32)
+    acc[:5, :, :3] = 0; acc[5:8, :, 0] = 1e9; acc[8, :, 1] = -3.0
+    for divisor, gamma in [(32.0, 1), (100.0, 1), (1.0, 0), (7.0, 0)]:
+        d = torch.from_numpy(acc).cuda()
+        stride = w * 4 + 64
+        out = torch.zeros(h * stride, dtype=torch.uint8, device="cuda")
+        rgb = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+        ctx.resolve_device(d.data_ptr(), w, h, divisor, gamma, out.data_ptr(), stride, rgb.data_ptr())
+        ctx.sync()
+        got = out.cpu().numpy().reshape(h, stride)[:, :w * 4].reshape(h, w, 4)
+        exp = oracle.resolve(acc[:, :, :3], divisor, gamma)
+        lin = acc[:, :, :3] / np.float32(divisor)
+        v = np.sqrt(np.maximum(lin, 0)) if gamma else lin
+        ref = (np.clip(v, 0, 1) * np.float32(255.0)).astype(np.uint8)
+        assert (got[:, :, 0] == ref[:, :, 2]).all() and (got[:, :, 1] == ref[:, :, 1]).all() and (got[:, :, 2] == ref[:, :, 0]).all()
+        assert (got[:, :, 3] == 255).all()
+        assert (got == exp).all()
+        assert np.array_equal(rgb.cpu().numpy().reshape(h, w, 3), lin)
+
+
+def test_error_paths(ctx):
+    s, cam, prm = scenes.scene04(4)
+    with pytest.raises(lib.RtError) as e:
+        ctx.render_path(s, cam, prm, 0, 10)
+    assert e.value.code == abi.RT_ERR_BAD_ARG
+    bad = scenes.Scene(); m = bad.diffuse((1, 1, 1)); bad.sphere(m, (0, 0, -3), 1.0); bad.prims[0].type = 9
+    with pytest.raises(lib.RtError) as e:
+        ctx.render_path(bad, cam, prm, 8, 8)
+    assert e.value.code == abi.RT_ERR_UNSUPPORTED
+    bad = scenes.Scene(); m = bad.diffuse((1, 1, 1)); bad.sphere(5, (0, 0, -3), 1.0)
+    with pytest.raises(lib.RtError) as e:
+        ctx.render_path(bad, cam, prm, 8, 8)
+    assert e.value.code == abi.RT_ERR_BAD_ARG
+    s1, cam1, prm1 = scenes.scene01()
+    with pytest.raises(lib.RtError) as e:                     # Phong material in a path render
+        ctx.render_path(s1, cam, prm, 8, 8)
+    assert e.value.code == abi.RT_ERR_UNSUPPORTED
+    with pytest.raises(lib.RtError) as e:                     # rectangle in a Whitted render
+        ctx.render_whitted(s, cam1, prm1, 8, 8)
+    assert e.value.code == abi.RT_ERR_UNSUPPORTED
+    prm1.max_depth = 99
+    with pytest.raises(lib.RtError) as e:
+        ctx.render_whitted(s1, cam1, prm1, 8, 8)
+    assert e.value.code == abi.RT_ERR_TOO_LARGE
+    # the context still works after errors
+    s, cam, prm = scenes.scene04(2)
+    assert ctx.render_path(s, cam, prm, 16, 16)["samples"] == 512
+
+
+# ---- BASELINE.json full sizes: size-independent properties -----------------------------------------------
+def test_full_size_04_4k_1024spp_properties(ctx):
+    """config 4 on one GPU: 3840x2160, 1024 spp.  Checks rays/sample, black-escape absence, sample-range linearity at full
+    size on a band of samples, and the image mean against a low-resolution converged oracle render."""
+    import torch
+    w, h, spp = 3840, 2160, 1024
+    s, cam, prm = scenes.scene04(spp, seed=1)
+    acc = torch.empty(h * w * 4, dtype=torch.float32, device="cuda")
+    ctx.path_accumulate_device(s, cam, prm, w, h, acc.data_ptr())
+    st = ctx.sync()
+    assert st["samples"] == w * h * spp
+    assert 6.84 < st["rays"] / st["samples"] < 6.87
+    a = acc.view(h, w, 4)
+    assert bool((a[:, :, 3] == spp).all()) and bool(torch.isfinite(a).all()) and float(a[:, :, :3].min()) >= 0.0
+    mean4k = (a[:, :, :3].double().mean(dim=(0, 1)) / spp).cpu().numpy()
+    so, camo, prmo = scenes.scene04(512, seed=77)
+    o = oracle.render_path(so, camo, prmo, 128, 72, threads=8)        # same aspect ratio
+    mo = (o["sum"] / 512).astype(np.float64).mean(axis=(0, 1))
+    assert np.allclose(mean4k, mo, rtol=0.02), (mean4k, mo)
+    # linearity on the full frame: samples [100,108) + [108,116) == [100,116)
+    p = [torch.empty_like(acc) for _ in range(3)]
+    for t, (b, e) in zip(p, [(100, 108), (108, 116), (100, 116)]):
+        ctx.path_accumulate_device(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, spp, seed=1, sample_begin=b, sample_end=e), w, h, t.data_ptr())
+        ctx.sync()
+    assert torch.allclose(p[0] + p[1], p[2], rtol=1e-5, atol=1e-5)
+
+
+def test_full_size_03_1080p_256spp_properties(ctx):
+    w, h, spp = 1920, 1080, 256
+    s, cam, prm = scenes.scene03(spp, seed=1)
+    g = ctx.render_path(s, cam, prm, w, h)
+    assert g["samples"] == w * h * spp and 2.0 < g["rays"] / g["samples"] < 2.4
+    so, camo, prmo = scenes.scene03(256, seed=9)
+    o = oracle.render_path(so, camo, prmo, 160, 90, threads=8)
+    assert np.allclose(g["rgb"].astype(np.float64).mean(axis=(0, 1)), (o["sum"] / 256).astype(np.float64).mean(axis=(0, 1)), rtol=0.01)
+    assert g["rgb"].min() >= 0.0 and g["rgb"].max() <= 1.0 + 1e-5     # sky and albedos are <= 1
+
+
+def test_full_size_02_4k_sweep_ray_counts(ctx):
+    w, h = 3840, 2160
+    for samples in (1, 16, 256):
+        s, cam, prm = scenes.scene02(samples)
+        g = ctx.render_whitted(s, cam, prm, w, h)
+        assert g["rays"] == w * h and g["shadow_rays"] == samples * w * h
