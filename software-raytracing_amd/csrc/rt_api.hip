@@ -115,7 +115,10 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         const float* f = P.f;
         switch (P.type) {
         case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], f[3])); break;
-        case RT_PRIM_PLANE:  H.geom.push_back(f4(f[3], f[4], f[5], f[3] * f[0] + f[4] * f[1] + f[5] * f[2])); break;
+        case RT_PRIM_PLANE:
+            if (variant == 0) { H.geom.push_back(f4(f[3], f[4], f[5], 0)); H.geom.push_back(f4(f[0], f[1], f[2], 0)); }   // strict form: n, p0
+            else H.geom.push_back(f4(f[3], f[4], f[5], f[3] * f[0] + f[4] * f[1] + f[5] * f[2]));
+            break;
         case RT_PRIM_RECT: {
             if (variant == 0) return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles exist only in the path-tracing examples");
             float neg[3] = {-f[5], -f[6], -f[7]}, pos[3] = {f[5], f[6], f[7]}, ri[9], rf[9];
@@ -338,7 +341,7 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
     A.width = width; A.height = height; A.max_depth = p->max_depth; A.shadow_samples = p->shadow_samples; A.seed = p->seed;
     float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 01 Main.cpp:333
     float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
-    A.inv_w2 = 2.0f / w; A.inv_h2 = 2.0f / h; A.kx = th * w / h; A.ky = th;
+    A.w = w; A.h = h; A.tan_half = th;
     if ((rc = begin_timed(c, st))) return rc;
     launch_whitted(p->shadow_samples > 0, D, A, (float4*)d_color, c->d_counters, st);
     HIPCHK(c, hipGetLastError());

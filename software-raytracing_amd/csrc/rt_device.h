@@ -11,7 +11,7 @@ namespace rt {
 //        and the sphere tMax rule depend on it) = {type, first geom float4 index, count, first prim index}
 // geom : per-type records, float4 units:
 //        sphere   1: (cx, cy, cz, r)
-//        plane    1: (nx, ny, nz, n.p0)
+//        plane    1: (nx, ny, nz, n.p0)            [Whitted scenes: 2: (n, 0) (p0, 0), see rt_strict.h]
 //        rect     5: (R00,R01,R02,px) (R10,R11,R12,py) (R20,R21,R22,pz) (hw,hh,nwx,nwy) (nwz,0,0,0)
 //                    R = GetRotationMat(-orientation), nw = GetRotationMat(orientation)*(0,0,1)
 //        triangle 4: (nx,ny,nz,n.v0) (v0x,v0y,v0z,0) (i00,i01,i02,0) (i10,i11,i12,0)

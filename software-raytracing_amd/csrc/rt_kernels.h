@@ -24,7 +24,7 @@ struct PathArgs {
 struct WhittedArgs {
     int width, height, max_depth, shadow_samples;
     uint32_t seed;
-    float inv_w2, inv_h2, kx, ky;
+    float w, h, tan_half;           // float(width), float(height), tanf(fovRadians/2) (01 Main.cpp:329-341)
 };
 
 void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st);

@@ -1,6 +1,7 @@
 // rt_kernels.hip - the tracing kernels (gfx950).  One thread per pixel(-sample slice); scene
 // primitives are wave-uniform and come through scalar loads; no MFMA (FP32 VALU-bound path).
 #include "rt_device.h"
+#include "rt_strict.h"
 #include "rt_kernels.h"
 
 namespace rt {
@@ -174,10 +175,7 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, f
     const uint32_t pixel = (uint32_t)(py * A.width + px);
     const uint32_t skey = rng_sample_key(rng_pixel_key(A.seed, pixel), 0U);
 
-    // primary ray (01 Main.cpp:340-344)
-    float x = fmaf((float)px + 0.5f, A.inv_w2, -1.0f) * A.kx;
-    float y = -fmaf((float)py + 0.5f, A.inv_h2, -1.0f) * A.ky;
-    f3 o = F3(0, 0, 0), d = normalize(F3(x, y, -1.0f));
+    f3 o = F3(0, 0, 0), d = strict::primary_dir(px, py, A.w, A.h, A.tan_half);     // 01 Main.cpp:340-344
     float weight = 1.0f, tmin = 0.0f;
     int depth = 0;
     uint32_t node = 1U, pending = 0U;
@@ -190,13 +188,13 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, f
         if (active) {
             bool done_node = true;   // pop after this node unless a child continues in place
             float t; int idx = -1;
-            if (depth <= A.max_depth) { ++rays; idx = closest_hit_fixed(S, o, d, tmin, 1000.0f, t); }   // :386-403
+            if (depth <= A.max_depth) { ++rays; idx = strict::closest_hit(S, o, d, tmin, 1000.0f, t); }          // :386-403
             if (idx < 0) {
                 acc = madd(sky, weight, acc);                                                            // :489-493
             } else {
                 int4 inf = S.info[idx];
-                f3 p = madd(d, t, o);
-                f3 n = (inf.x == PRIM_SPHERE) ? normalize(p - F3(S.geom[inf.y])) : F3(S.geom[inf.y]);   // Sphere.hpp:48, Plane.hpp:48
+                f3 p = strict::add(o, strict::muls(d, t));                                               // :414
+                f3 n = (inf.x == PRIM_SPHERE) ? strict::normalize(strict::sub(p, F3(S.geom[inf.y]))) : F3(S.geom[inf.y]);   // Sphere.hpp:48, Plane.hpp:48
                 float4 m0 = S.mats[inf.z * 3], m1 = S.mats[inf.z * 3 + 1], m2 = S.mats[inf.z * 3 + 2];
                 float p2s = m1.z, r2r = m1.w;
                 float wp = fmaxf(1.0f - p2s, 0.0f), wr = fmaxf(1.0f - r2r, 0.0f);
@@ -204,33 +202,28 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, f
                     f3 diffuse = F3(0, 0, 0), specular = F3(0, 0, 0);
                     for (int li = 0; li < S.n_lights; ++li) {
                         float4 l0 = S.lights[2 * li], l1 = S.lights[2 * li + 1];
-                        f3 to = F3(l0) - p;
-                        float len2 = dot(to, to);
-                        float len = sqrtf(len2);
-                        f3 tod = to * (len > 0.0f ? 1.0f / len : 0.0f);
+                        f3 lp = F3(l0);
+                        f3 to = strict::sub(lp, p);
+                        f3 tod = strict::normalize(to);
+                        float len = strict::length(to);
                         float intensity = 1.0f;
+                        bool skip = false;
                         if (!SOFT) {                                                                     // 01 :435-436
-                            if (depth + 1 <= A.max_depth) { ++srays; if (any_hit(S, p, tod, 0.01f, len)) intensity = 0.0f; }
-                        } else {                                                                         // 02 :452-467, :539-566
-                            if (depth + 1 <= A.max_depth) {
-                                float per = 1.0f / (float)A.shadow_samples;
-                                f3 lp = F3(l0);
-                                for (int i = 0; i < A.shadow_samples; ++i) {
-                                    uint32_t c = ((node * (uint32_t)S.n_lights + (uint32_t)li) * (uint32_t)A.shadow_samples + (uint32_t)i) * 4U;
-                                    f3 vb = F3(fmaf(2.0f, rng_u01(skey, c), -1.0f), fmaf(2.0f, rng_u01(skey, c + 1U), -1.0f), fmaf(2.0f, rng_u01(skey, c + 2U), -1.0f));
-                                    float rb = rng_u01(skey, c + 3U);
-                                    f3 pl = normalize(cross(tod, tod + vb));
-                                    f3 target = madd(pl, l0.w * rb, lp);
-                                    f3 sd = normalize(target - p);
-                                    ++srays;
-                                    if (any_hit(S, p, sd, 0.01f, len - l0.w)) intensity -= per;
-                                }
+                            if (depth + 1 <= A.max_depth) { ++srays; skip = strict::any_hit(S, p, tod, 0.01f, len); }
+                        } else if (depth + 1 <= A.max_depth) {                                           // 02 :452-467, :539-566
+                            float per = 1.0f / (float)A.shadow_samples;
+                            float tmax_s = len - l0.w;
+                            for (int i = 0; i < A.shadow_samples; ++i) {
+                                uint32_t c = ((node * (uint32_t)S.n_lights + (uint32_t)li) * (uint32_t)A.shadow_samples + (uint32_t)i) * 4U;
+                                f3 sd = strict::to_light_disk(p, lp, l0.w, rng_u01(skey, c), rng_u01(skey, c + 1U), rng_u01(skey, c + 2U), rng_u01(skey, c + 3U));
+                                ++srays;
+                                if (strict::any_hit(S, p, sd, 0.01f, tmax_s)) intensity -= per;
                             }
                         }
-                        float dd = fmaxf(0.0f, dot(tod, n));
-                        float sdot = fmaxf(0.0f, dot(reflect(-tod, n), -d));
+                        if (skip) continue;   // 01: an occluded light is skipped entirely
+                        float dd = fmaxf(0.0f, strict::dot(tod, n));
+                        float sdot = fmaxf(0.0f, strict::dot(strict::reflect(-tod, n), -d));
                         float sp = powf(sdot, m1.y);
-                        if (!SOFT && intensity == 0.0f) continue;   // 01: an occluded light is skipped entirely
                         diffuse = madd(F3(l1), dd * intensity, diffuse);
                         specular = madd(F3(l1), sp * intensity, specular);
                     }
@@ -240,12 +233,12 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, f
                 if (p2s < 1.0f) {                                                                        // :450-481
                     bool do_refl = r2r > 0.0f, do_refr = r2r < 1.0f;
                     float w_refl = weight * wp * (1.0f - wr), w_refr = weight * wp * wr;
-                    f3 d_refl = reflect(d, n), d_refr = d;
+                    f3 d_refl = strict::normalize(strict::reflect(d, n)), d_refr = d;
                     if (do_refr) {                                                                       // :467-475
                         float eta = m2.x;
                         f3 nn = n;
-                        if (dot(n, d) > 0.0f) { nn = -n; eta = 1.0f / eta; }
-                        d_refr = refract(d, nn, eta);
+                        if (strict::dot(n, -d) < 0.0f) { nn = -n; eta = 1.0f / eta; }
+                        d_refr = strict::normalize(strict::refract(d, nn, eta));
                     }
                     int cd = depth + 1;
                     if (do_refl && do_refr) {   // park the refraction child in the slot of its depth
@@ -256,8 +249,8 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, f
                     }
                     if (do_refl || do_refr) {
                         o = p; tmin = 0.001f; depth = cd;
-                        if (do_refl) { d = normalize(d_refl); weight = w_refl; node = node * 2U; }
-                        else         { d = normalize(d_refr); weight = w_refr; node = node * 2U + 1U; }
+                        if (do_refl) { d = d_refl; weight = w_refl; node = node * 2U; }
+                        else         { d = d_refr; weight = w_refr; node = node * 2U + 1U; }
                         done_node = false;
                     }
                 }
@@ -268,7 +261,7 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, f
                     int k = 31 - __clz((int)pending);
                     pending &= ~(1U << k);
                     o = F3(stk[k][0][tid], stk[k][1][tid], stk[k][2][tid]);
-                    d = normalize(F3(stk[k][3][tid], stk[k][4][tid], stk[k][5][tid]));
+                    d = F3(stk[k][3][tid], stk[k][4][tid], stk[k][5][tid]);
                     weight = stk[k][6][tid]; node = __float_as_uint(stk[k][7][tid]);
                     depth = k; tmin = 0.001f;
                 }
