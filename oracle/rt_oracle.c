@@ -187,6 +187,12 @@ static inline uint32_t rng_draw(uint32_t sample_key, uint32_t ctr) {
 static inline float rng_u01(uint32_t sample_key, uint32_t ctr) { /* uniform in [0,1), 24 bits */
     return (float)(rng_draw(sample_key, ctr) >> 8) * (1.0f / 16777216.0f);
 }
+/* two 16-bit uniforms from ONE draw: a = low half, b = high half, each k/65536 */
+static inline void rng_pair(uint32_t sample_key, uint32_t ctr, float* a, float* b) {
+    uint32_t r = rng_draw(sample_key, ctr);
+    *a = (float)(r & 0xFFFFU) * (1.0f / 65536.0f);
+    *b = (float)(r >> 16) * (1.0f / 65536.0f);
+}
 uint32_t orc_rng_draw(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t ctr) {
     return rng_draw(rng_sample_key(rng_pixel_key(seed, pixel), sample), ctr);
 }
@@ -313,15 +319,15 @@ typedef struct {
     counters_t* cnt;
 } wctx_t;
 
-/* RandomVectorToLightSphere (02 Main.cpp:539-566); draws: vBias x,y,z in U(-1,1), rBias in U(0,1). */
+/* RandomVectorToLightSphere (02 Main.cpp:539-566); vBias x,y,z in U(-1,1), rBias in U(0,1): two pair draws. */
 static v3 random_vector_to_light(const wctx_t* w, v3 p, const rt_light* l, uint32_t ctr_base) {
     v3 lp = pv(l->position);
     v3 to = normalize3(sub(lp, p));
     /* uniform_real_distribution(a,b): (b-a)*u + a */
-    v3 vb = V(2.0f * rng_u01(w->sample_key, ctr_base + 0) + -1.0f,
-              2.0f * rng_u01(w->sample_key, ctr_base + 1) + -1.0f,
-              2.0f * rng_u01(w->sample_key, ctr_base + 2) + -1.0f);
-    float rb = rng_u01(w->sample_key, ctr_base + 3);
+    float u0, u1, u2, rb;
+    rng_pair(w->sample_key, ctr_base + 0, &u0, &u1);
+    rng_pair(w->sample_key, ctr_base + 2, &u2, &rb);
+    v3 vb = V(2.0f * u0 + -1.0f, 2.0f * u1 + -1.0f, 2.0f * u2 + -1.0f);
     v3 pl = normalize3(cross3(to, add(to, vb)));
     v3 target = add(lp, muls(muls(pl, l->radius), rb));
     return normalize3(sub(target, p));
@@ -484,18 +490,20 @@ static float reflectance(v3 v, v3 n, float ratio) {
 
 /* Material::scatter of 03 (Materials.hpp:50-75,142-169,233-265) and materials::*::scatteredRay of
  * 04 (Diffuse.hpp:64-82, Metal.hpp:67-88, Refractive.hpp:80-104).  Returns the scattered ray and
- * attenuation.  RNG counters at recursion depth k: 4(k+1)+{0: fi, 1: theta/height, 2: Schlick}. */
+ * attenuation.  RNG counters at recursion depth k: draw 4(k+1) gives the pair (fi, theta/height), draw 4(k+1)+2 the Schlick threshold. */
 static ray_t scatter(const pctx_t* pc, const rt_material* m, const ray_t* in, const hit_t* h, int depth, v3* att) {
     uint32_t c0 = 4U * ((uint32_t)depth + 1U);
+    float ua, ub;
+    rng_pair(pc->sample_key, c0, &ua, &ub);   /* (phi, theta/height) */
     v3 dir;
     switch (m->type) {
     case RT_MAT_DIFFUSE:
         if (pc->variant == RT_PATH_SKY) {
-            dir = rnd_hemisphere_03(h->normal, 90.0f, rng_u01(pc->sample_key, c0), rng_u01(pc->sample_key, c0 + 1));
+            dir = rnd_hemisphere_03(h->normal, 90.0f, ua, ub);
             *att = pv(m->albedo);
             return make_ray(h->point, dir);
         } else {
-            dir = rnd_hemisphere_04(h->normal, 90.0f, rng_u01(pc->sample_key, c0), rng_u01(pc->sample_key, c0 + 1));
+            dir = rnd_hemisphere_04(h->normal, 90.0f, ua, ub);
             ray_t r = make_ray(h->point, dir);
             float a = dot3(r.d, h->normal); if (!(0.0f < a)) a = 0.0f;
             *att = muls(pv(m->albedo), a);
@@ -505,11 +513,11 @@ static ray_t scatter(const pctx_t* pc, const rt_material* m, const ray_t* in, co
         dir = reflect3(in->d, h->normal);
         if (pc->variant == RT_PATH_SKY) {
             if (m->roughness > 0.0f)
-                dir = rnd_hemisphere_03(dir, 60.0f * m->roughness, rng_u01(pc->sample_key, c0), rng_u01(pc->sample_key, c0 + 1));
+                dir = rnd_hemisphere_03(dir, 60.0f * m->roughness, ua, ub);
             *att = pv(m->albedo);
             return make_ray(h->point, dir);
         } else {
-            dir = rnd_hemisphere_04(dir, 60.0f * m->roughness, rng_u01(pc->sample_key, c0), rng_u01(pc->sample_key, c0 + 1));
+            dir = rnd_hemisphere_04(dir, 60.0f * m->roughness, ua, ub);
             ray_t r = make_ray(h->point, dir);
             float a = dot3(r.d, h->normal); if (!(0.0f < a)) a = 0.0f;
             *att = muls(pv(m->albedo), a);
@@ -587,7 +595,7 @@ int orc_render_path(const rt_scene* scene, const rt_camera* cam, const rt_path_p
             for (int s = s0; s < s1; s++) {
                 pc.sample_key = rng_sample_key(pkey, (uint32_t)s);
                 float bx = 0.5f, by = 0.5f;
-                if (prm->spp > 1) { bx = rng_u01(pc.sample_key, 0); by = rng_u01(pc.sample_key, 1); } /* :331 */
+                if (prm->spp > 1) rng_pair(pc.sample_key, 0, &bx, &by);                       /* :331 */
                 float x = (2.0f * ((float)i + bx) / w - 1.0f) * tanf(fov_rad / 2.0f) * w / h;
                 float y = -(2.0f * ((float)j + by) / h - 1.0f) * tanf(fov_rad / 2.0f);
                 m3 rot = rotation_mat(corient);                                           /* :338 */

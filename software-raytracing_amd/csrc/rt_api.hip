@@ -47,6 +47,7 @@ struct rt_ctx {
     rt_stats stats{};
     std::string err;
     int regen_threshold_override = -1;
+    int debug_flags = 0;
 };
 
 namespace {
@@ -69,6 +70,7 @@ void rotation_mat(const float deg[3], float out[9]) {
 struct HostScene {
     std::vector<int4> runs, info;
     std::vector<float4> geom, mats, lights;
+    int has_aa = 0;
 };
 
 float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
@@ -112,12 +114,19 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         if (P.material >= s->n_materials) return fail(c, RT_ERR_BAD_ARG, "prim " + std::to_string(i) + ": material index out of range");
         int mat = P.material < 0 ? s->n_materials : P.material;
         int gi = (int)H.geom.size();
+        int dtype = P.type;
         const float* f = P.f;
         switch (P.type) {
-        case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], f[3])); break;
+        case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], variant == 0 ? f[3] : f[3] * f[3])); break;
         case RT_PRIM_PLANE:
             if (variant == 0) { H.geom.push_back(f4(f[3], f[4], f[5], 0)); H.geom.push_back(f4(f[0], f[1], f[2], 0)); }   // strict form: n, p0
-            else H.geom.push_back(f4(f[3], f[4], f[5], f[3] * f[0] + f[4] * f[1] + f[5] * f[2]));
+            else {
+                int axis = -1;    // unit normal exactly +-e_axis: shares 1/d per ray (bit-identical to the general form)
+                for (int a = 0; a < 3; ++a)
+                    if (fabsf(f[3 + a]) == 1.0f && f[3 + (a + 1) % 3] == 0.0f && f[3 + (a + 2) % 3] == 0.0f) axis = a;
+                if (axis >= 0) { H.geom.push_back(f4(f[axis], f[3 + axis], 0, 0)); dtype = PRIM_AAPLANE_X + axis; H.has_aa = 1; }
+                else H.geom.push_back(f4(f[3], f[4], f[5], f[3] * f[0] + f[4] * f[1] + f[5] * f[2]));
+            }
             break;
         case RT_PRIM_RECT: {
             if (variant == 0) return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles exist only in the path-tracing examples");
@@ -143,9 +152,9 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
             break; }
         default: return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": unknown type " + std::to_string(P.type));
         }
-        H.info.push_back(make_int4(P.type, gi, mat, (int)P.flags));
-        if (!H.runs.empty() && H.runs.back().x == P.type) H.runs.back().z++;
-        else H.runs.push_back(make_int4(P.type, gi, 1, i));
+        H.info.push_back(make_int4(dtype, gi, mat, (int)P.flags));
+        if (!H.runs.empty() && H.runs.back().x == dtype) H.runs.back().z++;
+        else H.runs.push_back(make_int4(dtype, gi, 1, i));
     }
     for (int l = 0; l < s->n_lights; ++l) {
         const rt_light& L = s->lights[l];
@@ -156,7 +165,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
 
 // Packs the HostScene into one pinned blob, uploads it and fills DevScene with device pointers.
 int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
-    auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
     size_t o_runs = 0, o_geom = pad(o_runs + H.runs.size() * 16), o_info = pad(o_geom + H.geom.size() * 16),
            o_mats = pad(o_info + H.info.size() * 16), o_lights = pad(o_mats + H.mats.size() * 16), total = pad(o_lights + H.lights.size() * 16 + 16);
     if (total > c->h_stage_cap) {
@@ -173,10 +182,11 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     memcpy(h + o_info, H.info.data(), H.info.size() * 16); memcpy(h + o_mats, H.mats.data(), H.mats.size() * 16);
     memcpy(h + o_lights, H.lights.data(), H.lights.size() * 16);
     HIPCHK(c, hipMemcpyAsync(c->scene_buf.p, h, total, hipMemcpyHostToDevice, st));
-    char* d = (char*)c->scene_buf.p;
-    D.runs = (const int4*)(d + o_runs); D.geom = (const float4*)(d + o_geom); D.info = (const int4*)(d + o_info);
-    D.mats = (const float4*)(d + o_mats); D.lights = (const float4*)(d + o_lights);
+    D.blob = (const float4*)c->scene_buf.p;
+    D.off_runs = (int)(o_runs / 16); D.off_geom = (int)(o_geom / 16); D.off_info = (int)(o_info / 16);
+    D.off_mats = (int)(o_mats / 16); D.off_lights = (int)(o_lights / 16); D.total_f4 = (int)(total / 16);
     D.n_runs = (int)H.runs.size(); D.n_prims = (int)H.info.size(); D.n_mats = (int)H.mats.size() / 3; D.n_lights = (int)H.lights.size() / 2;
+    D.has_aa = H.has_aa;
     return RT_OK;
 }
 
@@ -302,7 +312,8 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
 
     PathArgs A{};
     A.width = width; A.height = height; A.sample_begin = s0; A.sample_end = s1; A.max_depth = p->max_depth;
-    A.jitter = p->spp > 1; A.seed = p->seed; A.t_min = p->t_min; A.t_max = p->t_max;
+    A.jitter = p->spp > 1; A.seed = p->seed; A.t_min = p->t_min; A.t_min_pos = p->t_min > 0.0f ? p->t_min : 1.401298464e-45f; A.t_max = p->t_max;
+    A.debug_flags = c->debug_flags;
     A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : (p->variant == RT_PATH_LIGHTS ? 16 : 8);
     float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 03 Main.cpp:317
     float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
@@ -398,6 +409,7 @@ int32_t rt_render_path(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, c
 }
 
 // test/bench hook: regeneration threshold (idle lanes per wave); <0 restores the default. Not part of rt_mi355.h.
+int32_t rt_debug_set_flags(rt_ctx* c, int32_t f) { if (!c) return RT_ERR_BAD_ARG; c->debug_flags = f; return RT_OK; }
 int32_t rt_debug_set_regen_threshold(rt_ctx* c, int32_t n) { if (!c) return RT_ERR_BAD_ARG; c->regen_threshold_override = n; return RT_OK; }
 
 } // extern "C"

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include "../../include/rt_mi355.h"
 
+#define RT_LDS_SCENE_MAX_BYTES (48 * 1024)
+
 namespace rt {
 struct DevScene;
 
@@ -14,8 +16,9 @@ struct PathArgs {
     int max_depth;
     int jitter;                     // spp > 1 (03 Main.cpp:331)
     int regen_threshold;            // idle lanes per wave that trigger a regeneration pass
+    int debug_flags;                // bit1: no LDS staging (A/B switch)
     uint32_t seed;
-    float t_min, t_max;
+    float t_min, t_min_pos, t_max;  // t_min_pos = max(t_min, smallest positive float): "t > 0 && t >= tMin" in one compare
     float inv_w2, inv_h2, kx, ky;   // 2/w, 2/h, tan(fov/2)*w/h, tan(fov/2)
     float r[9];                     // GetRotationMat(orientation), row-major
     float px, py, pz;

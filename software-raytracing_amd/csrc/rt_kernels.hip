@@ -13,8 +13,16 @@ namespace rt {
 // and a wave regenerates only when enough of its lanes are idle (ballot), so lanes stay busy
 // without paying the camera code on every iteration.
 // =================================================================================================
-template <int VARIANT>
-__global__ __launch_bounds__(256) void k_path(DevScene S, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+template <int VARIANT, bool LDS>
+__global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    extern __shared__ float4 smem[];
+    const float4* base = SD.blob;
+    if (LDS) {   // stage the whole flattened scene in LDS: primitive operands then arrive in VGPRs (ds_read), not SGPRs
+        for (int i = threadIdx.x; i < SD.total_f4; i += 256) smem[i] = SD.blob[i];
+        __syncthreads();
+        base = smem;
+    }
+    const Scn S = scn_over(SD, base);
     int px, py;
     bool inside = pixel_of_thread(A.width, A.height, px, py);
     const int slice = blockIdx.y;
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(256) void k_path(DevScene S, PathArgs A, float4* __
             if (want) {   // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369)
                 skey = rng_sample_key(pkey, (uint32_t)s_next);
                 float bx = 0.5f, by = 0.5f;
-                if (A.jitter) { bx = rng_u01(skey, 0); by = rng_u01(skey, 1); }
+                if (A.jitter) rng_pair(skey, 0U, bx, by);
                 float x = fmaf((float)px + bx, A.inv_w2, -1.0f) * A.kx;
                 float y = -fmaf((float)py + by, A.inv_h2, -1.0f) * A.ky;
                 f3 v = F3(x, y, -1.0f);
@@ -55,7 +63,7 @@ __global__ __launch_bounds__(256) void k_path(DevScene S, PathArgs A, float4* __
             // TraceTay: one scene query (03 Main.cpp:392, 04 Main.cpp:447)
             ++rays;
             float t;
-            int idx = closest_hit_shrinking(S, o, d, A.t_min, A.t_max, t);
+            int idx = closest_hit_shrinking(S, SD.has_aa != 0, o, d, A.t_min, A.t_min_pos, A.t_max, t);
             if (idx < 0) {
                 if (VARIANT == 3) {   // sky: Mix(white, (0.5,0.7,1), 0.5*(d.y+1)) (03 Main.cpp:430-432)
                     float h = 0.5f * (d.y + 1.0f);
@@ -75,6 +83,10 @@ __global__ __launch_bounds__(256) void k_path(DevScene S, PathArgs A, float4* __
                     float4 r2 = S.geom[inf.y + 2], r3 = S.geom[inf.y + 3], r4 = S.geom[inf.y + 4];
                     n = F3(r3.z, r3.w, r4.x);
                     back = dot(F3(r2), d) > 0.0f;
+                } else if (inf.x >= PRIM_AAPLANE_X) { // plane with normal +-e_axis (04 Scene/Plane.hpp:55-66)
+                    float sgn = S.geom[inf.y].y;
+                    n = F3(inf.x == PRIM_AAPLANE_X ? sgn : 0.0f, inf.x == PRIM_AAPLANE_Y ? sgn : 0.0f, inf.x == PRIM_AAPLANE_Z ? sgn : 0.0f);
+                    back = dot(d, n) > 0.0f;
                 } else {                             // plane 04 Scene/Plane.hpp:55-66; triangle likewise
                     n = F3(S.geom[inf.y]);
                     back = dot(d, n) > 0.0f;
@@ -88,12 +100,15 @@ __global__ __launch_bounds__(256) void k_path(DevScene S, PathArgs A, float4* __
                     if (m2.y >= 0.0f) {
                         // RndHemisphereVec (03 Utils.h:64-88) / RndHemisphereVec3 (04 Utils.h:132-157)
                         uint32_t c0 = 4U * ((uint32_t)depth + 1U);
-                        float u_fi = rng_u01(skey, c0), u_th = rng_u01(skey, c0 + 1U);
-                        f3 b = cross(axis, axis + F3(0.01f, 0.01f, 0.01f));
+                        float u_fi, u_th;
+                        rng_pair(skey, c0, u_fi, u_th);
+                        // b = Normalize(Cross(dir, dir + 0.01)) = Normalize(Cross(dir, (1,1,1))): the 0.01 and dir x dir cancel;
+                        // c = Cross(dir, b) is already unit (dir, b orthonormal), so the reference's second Normalize is a no-op
+                        f3 b = F3(axis.y - axis.z, axis.z - axis.x, axis.x - axis.y);
                         float bl2 = dot(b, b);
                         bool degenerate = !(bl2 > 0.0f);
                         b = b * (degenerate ? 0.0f : rsq_fast(bl2));
-                        f3 c = normalize(cross(axis, b));
+                        f3 c = cross(axis, b);
                         const float fi_rev = (float)((360.0 / 57.2958f) / 6.283185307179586);   // fi/(2*pi)
                         float cf = __builtin_amdgcn_cosf(u_fi * fi_rev), sf = __builtin_amdgcn_sinf(u_fi * fi_rev);
                         float ct, st;
@@ -138,10 +153,17 @@ __global__ __launch_bounds__(256) void k_path(DevScene S, PathArgs A, float4* __
     wave_add_u64(counters + 0, rays);
 }
 
-void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st) {
+template <int VARIANT>
+static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 15) / 16), n_slices);
-    if (variant == 3) hipLaunchKernelGGL(k_path<3>, grid, dim3(256), 0, st, S, A, out, counters);
-    else              hipLaunchKernelGGL(k_path<4>, grid, dim3(256), 0, st, S, A, out, counters);
+    size_t bytes = (size_t)S.total_f4 * sizeof(float4);
+    bool lds = bytes <= RT_LDS_SCENE_MAX_BYTES && !(A.debug_flags & 2);   // small scene: LDS-resident
+    if (lds) hipLaunchKernelGGL((k_path<VARIANT, true>), grid, dim3(256), bytes, st, S, A, out, counters);
+    else     hipLaunchKernelGGL((k_path<VARIANT, false>), grid, dim3(256), 0, st, S, A, out, counters);   // large scene: scalar loads from the global blob
+}
+void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st) {
+    if (variant == 3) launch_path_v<3>(S, A, out, n_slices, counters, st);
+    else              launch_path_v<4>(S, A, out, n_slices, counters, st);
 }
 
 // Sum the per-slice partial images in a fixed order (deterministic), out = float4(sum rgb, samples).
@@ -164,7 +186,8 @@ void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* o
 // =================================================================================================
 #define WBLOCK 128
 template <bool SOFT>
-__global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    const Scn S = scn_over(SD, SD.blob);
     __shared__ float stk[RT_WHITTED_MAX_DEPTH_LIMIT + 1][8][WBLOCK];   // slot k: o(3) d(3) weight node
     const int tid = threadIdx.x;
     // 16x8 pixels per 128-thread block, 8x8 per wave
@@ -215,7 +238,9 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene S, WhittedArgs A, f
                             float tmax_s = len - l0.w;
                             for (int i = 0; i < A.shadow_samples; ++i) {
                                 uint32_t c = ((node * (uint32_t)S.n_lights + (uint32_t)li) * (uint32_t)A.shadow_samples + (uint32_t)i) * 4U;
-                                f3 sd = strict::to_light_disk(p, lp, l0.w, rng_u01(skey, c), rng_u01(skey, c + 1U), rng_u01(skey, c + 2U), rng_u01(skey, c + 3U));
+                                float u0, u1, u2, u3;
+                                rng_pair(skey, c, u0, u1); rng_pair(skey, c + 2U, u2, u3);
+                                f3 sd = strict::to_light_disk(p, lp, l0.w, u0, u1, u2, u3);
                                 ++srays;
                                 if (strict::any_hit(S, p, sd, 0.01f, tmax_s)) intensity -= per;
                             }

@@ -84,12 +84,12 @@ static __device__ __forceinline__ bool hit_tri(const float4* __restrict__ g, f3 
 
 // Whitted scene layout: planes carry a second float4 with the point p0 (geom stride 2), see rt_api.hip.
 // Closest hit of 01/02 TraceTay (01 Main.cpp:389-403): same [tMin,tMax] for every element, strict t < nearest.
-static __device__ __forceinline__ int closest_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax, float& t_out) {
+static __device__ __forceinline__ int closest_hit(const Scn& S, f3 o, f3 d, float tmin, float tmax, float& t_out) {
     int best = -1;
     float nearest = 3.402823466e+38f;
     for (int r = 0; r < S.n_runs; ++r) {
         int4 run = S.runs[r];
-        const float4* __restrict__ g = S.geom + run.y;
+        const float4* g = S.geom + run.y;
         if (run.x == PRIM_SPHERE) {
             for (int i = 0; i < run.z; ++i) { float t; if (hit_sphere(g[i], o, d, tmin, tmax, t) && t < nearest) { nearest = t; best = run.w + i; } }
         } else if (run.x == PRIM_PLANE) {
@@ -102,11 +102,11 @@ static __device__ __forceinline__ int closest_hit(const DevScene& S, f3 o, f3 d,
     return best;
 }
 // Shadow form (outColor == nullptr): any element inside [tMin,tMax].
-static __device__ __forceinline__ bool any_hit(const DevScene& S, f3 o, f3 d, float tmin, float tmax) {
+static __device__ __forceinline__ bool any_hit(const Scn& S, f3 o, f3 d, float tmin, float tmax) {
     bool hit = false;
     for (int r = 0; r < S.n_runs; ++r) {
         int4 run = S.runs[r];
-        const float4* __restrict__ g = S.geom + run.y;
+        const float4* g = S.geom + run.y;
         if (run.x == PRIM_SPHERE) {
             for (int i = 0; i < run.z; ++i) { float t; hit |= hit_sphere(g[i], o, d, tmin, tmax, t); }
         } else if (run.x == PRIM_PLANE) {

@@ -44,6 +44,7 @@ def load():
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.rt_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_debug_set_regen_threshold.argtypes = [C.c_void_p, C.c_int32]
+        L.rt_debug_set_flags.argtypes = [C.c_void_p, C.c_int32]
         _LIB = L
     return _LIB
 
@@ -114,3 +115,6 @@ class Context:
 
     def set_regen_threshold(self, n):
         self._chk(self.L.rt_debug_set_regen_threshold(self.h, n))
+
+    def set_debug_flags(self, f):
+        self._chk(self.L.rt_debug_set_flags(self.h, f))

@@ -4,9 +4,14 @@
 #include <cstdio>
 #include <vector>
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
 #define ITER 4096
 #define CHAINS 8
 
+static __device__ inline float tof(float v) { return v; }
+static __device__ inline float tof(unsigned v) { return (float)v; }
+static __device__ inline float tof(float2_t v) { return v.x + v.y; }
+static __device__ inline float2_t mk2(float a, float b) { float2_t v; v.x = a; v.y = b; return v; }
 #define KERNEL(NAME, DECL, BODY)                                                              \
     __global__ __launch_bounds__(256) void NAME(float* out, float a, float b) {               \
         DECL;                                                                                 \
@@ -14,7 +19,7 @@
             _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) { BODY; }                      \
         }                                                                                     \
         float s = 0;                                                                          \
-        for (int c = 0; c < CHAINS; ++c) s += (float)x[c];                                    \
+        for (int c = 0; c < CHAINS; ++c) s += tof(x[c]);                                    \
         out[blockIdx.x * 256 + threadIdx.x] = s;                                              \
     }
 
@@ -44,6 +49,23 @@ KERNEL(k_mov, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx
 KERNEL(k_mulhi, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
 KERNEL(k_xad, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
 KERNEL(k_med3, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b)))
+
+KERNEL(k_add_s, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_add_f32 %0, %1, %0" : "+v"(x[c]) : "s"(a)))
+KERNEL(k_mul_s, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x[c]) : "s"(a)))
+KERNEL(k_sub_s, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_sub_f32 %0, %1, %0" : "+v"(x[c]) : "s"(a)))
+KERNEL(k_fmac_s, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[c]) : "s"(a), "v"(b)))
+KERNEL(k_fma_k, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_max, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_cmp_s, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cmp_lt_f32 vcc, %1, %0" : "+v"(x[c]) : "s"(a) : "vcc"))
+KERNEL(k_cmp64, float x[CHAINS]; unsigned long long m; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cmp_lt_f32_e64 %1, %0, %2" : "+v"(x[c]), "=s"(m) : "v"(a)))
+KERNEL(k_cmpx, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cmp_class_f32 vcc, %0, %1" : "+v"(x[c]) : "v"(a) : "vcc"))
+KERNEL(k_and, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_bfi, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
+KERNEL(k_addu, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_lshladd, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_pkmul, float2_t x[CHAINS]; float2_t av = mk2(a, b); for (int c = 0; c < CHAINS; ++c) x[c] = mk2(threadIdx.x, c), asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x[c]) : "v"(av)))
+KERNEL(k_pkadd, float2_t x[CHAINS]; float2_t av = mk2(a, b); for (int c = 0; c < CHAINS; ++c) x[c] = mk2(threadIdx.x, c), asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x[c]) : "v"(av)))
+
 __global__ __launch_bounds__(256) void k_clock(float* out, float a, float b) {
     float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c;
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -57,7 +79,6 @@ __global__ __launch_bounds__(256) void k_clock(float* out, float a, float b) {
     if (blockIdx.x == 100 && threadIdx.x == 0) printf("in-kernel clock under v_fma load: %.1f MHz (cycles %llu, realtime ticks %llu)\n", 100.0 * (double)(t1 - t0) / (double)(r1 - r0), t1 - t0, r1 - r0);
 }
 
-typedef float float2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_pkfma(float* out, float a, float b) {
     float2_t x[CHAINS], av = {a, a}, bv = {b, b};
     for (int c = 0; c < CHAINS; ++c) x[c] = (float2_t){(float)threadIdx.x, (float)c};
@@ -95,6 +116,10 @@ int main() {
     run("cndmask_e64(sgpr)", k_cnd64, d, 1); run("cmp+cndmask", k_cmpcnd, d, 2); run("v_min_f32", k_min, d, 1); run("v_add_f32", k_add, d, 1);
     run("v_fmac_f32", k_fmac, d, 2); run("v_fma sgpr", k_fmas, d, 2); run("v_rsq_f32", k_rsq, d, 1); run("v_mov_b32", k_mov, d, 1);
     run("v_mul_hi_u32", k_mulhi, d, 1); run("v_xad_u32", k_xad, d, 1); run("v_med3_f32", k_med3, d, 1);
+    run("v_add_f32 sgpr", k_add_s, d, 1); run("v_mul_f32 sgpr", k_mul_s, d, 1); run("v_sub_f32 sgpr", k_sub_s, d, 1); run("v_fmac sgpr", k_fmac_s, d, 2);
+    run("v_fma const", k_fma_k, d, 2); run("v_max_f32", k_max, d, 1); run("v_cmp sgpr", k_cmp_s, d, 1); run("v_cmp_e64->s", k_cmp64, d, 1);
+    run("v_cmp_class", k_cmpx, d, 1); run("v_and_b32", k_and, d, 1); run("v_bfi_b32", k_bfi, d, 1); run("v_add_u32", k_addu, d, 1); run("v_lshl_add_u32", k_lshladd, d, 1);
+    run("v_pk_mul_f32", k_pkmul, d, 2); run("v_pk_add_f32", k_pkadd, d, 2);
     hipLaunchKernelGGL(k_clock, dim3(2048), dim3(256), 0, 0, d, 1.0001f, 0.5f); hipDeviceSynchronize();
     hipFree(d);
     return 0;
