@@ -1,0 +1,71 @@
+// headless.hpp - what replaces the Win32 shell of the reference examples: command-line size instead of the window's
+// client rectangle (784x561 is the client area of the reference's 800x600 window) and a binary PPM file instead of
+// PresentFrame (Sources/01_Basic/Main.cpp:272-310).
+#pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+struct Options {
+    unsigned width = 784, height = 561, samples = 0, seed = 1;
+    std::string out, dump;
+};
+
+inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
+    Options o;
+    o.samples = defaultSamples;
+    for (int i = 1; i < argc; ++i) {
+        auto value = [&](const char* name) -> const char* {
+            if (std::strcmp(argv[i], name) != 0) return nullptr;
+            if (i + 1 >= argc) throw std::runtime_error(std::string("ERROR: missing value after ") + name);
+            return argv[++i];
+        };
+        if (const char* v = value("--width")) o.width = static_cast<unsigned>(std::atoi(v));
+        else if (const char* v = value("--height")) o.height = static_cast<unsigned>(std::atoi(v));
+        else if (const char* v = value("--samples")) o.samples = static_cast<unsigned>(std::atoi(v));
+        else if (const char* v = value("--seed")) o.seed = static_cast<unsigned>(std::strtoul(v, nullptr, 10));
+        else if (const char* v = value("--out")) o.out = v;
+        else if (const char* v = value("--dump-scene")) o.dump = v;
+        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene)");
+    }
+    return o;
+}
+
+// P6 PPM, top row first, R,G,B from the B,G,R,reserved quads
+template <class FrameBuffer> inline void WriteFrame(FrameBuffer& fb, const std::string& path) {
+    if (path.empty()) return;
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("ERROR: can't open " + path);
+    std::fprintf(f, "P6\n%u %u\n255\n", fb.getWidth(), fb.getHeight());
+    std::string row(static_cast<size_t>(fb.getWidth()) * 3, '\0');
+    for (unsigned y = 0; y < fb.getHeight(); ++y) {
+        const auto* px = fb[static_cast<int>(y)];
+        for (unsigned x = 0; x < fb.getWidth(); ++x) {
+            row[3 * x + 0] = static_cast<char>(px[x].rgbRed); row[3 * x + 1] = static_cast<char>(px[x].rgbGreen); row[3 * x + 2] = static_cast<char>(px[x].rgbBlue);
+        }
+        std::fwrite(row.data(), 1, row.size(), f);
+    }
+    std::fclose(f);
+}
+
+// Raw flat records (counts, then rt_prim[], rt_material[], rt_light[]) for tests/test_host_mirror.py; needs no GPU.
+inline void DumpFlat(const rtbackend::Flat& flat, const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("ERROR: can't open " + path);
+    const int32_t n[3] = {static_cast<int32_t>(flat.prims.size()), static_cast<int32_t>(flat.mats.size()), static_cast<int32_t>(flat.lights.size())};
+    std::fwrite(n, sizeof n, 1, f);
+    std::fwrite(flat.prims.data(), sizeof(rt_prim), flat.prims.size(), f);
+    std::fwrite(flat.mats.data(), sizeof(rt_material), flat.mats.size(), f);
+    std::fwrite(flat.lights.data(), sizeof(rt_light), flat.lights.size(), f);
+    std::fclose(f);
+}
+
+inline void PrintBackendStats() {
+    rt_stats st{};
+    if (rt_get_stats(rtbackend::context(), &st) == RT_OK)
+        std::cout << "INFO: rays " << st.rays << ", shadow rays " << st.shadow_rays << ", samples " << st.samples
+                  << ", kernel " << st.kernel_ms << " ms, call " << st.total_ms << " ms" << std::endl;
+}

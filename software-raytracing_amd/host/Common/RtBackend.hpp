@@ -1,0 +1,40 @@
+// RtBackend.hpp - what the four Render() wrappers share: the process-wide rt_ctx, error -> std::runtime_error
+// (the reference's main() catches std::exception, 01_Basic/Main.cpp:230-233), and RGBQUAD for non-Windows hosts.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../../include/rt_mi355.h"
+#include "ImageBuffer.hpp"
+
+#ifndef _WINDOWS_
+struct RGBQUAD { uint8_t rgbBlue, rgbGreen, rgbRed, rgbReserved; };   // wingdi.h layout: B, G, R, reserved
+using BYTE = uint8_t;
+#endif
+static_assert(sizeof(RGBQUAD) == 4, "RGBQUAD must be 4 bytes: the kernels write B,G,R,255 straight into it");
+
+namespace rtbackend {
+inline rt_ctx* context() {
+    static rt_ctx* ctx = rt_create(-1);
+    if (!ctx) throw std::runtime_error(std::string("ERROR: no MI355X tracing backend: ") + rt_last_error(nullptr));
+    return ctx;
+}
+inline void check(int32_t rc) { if (rc != RT_OK) throw std::runtime_error(std::string("ERROR: rt_mi355: ") + rt_last_error(context())); }
+inline rt_image image_of(ImageBuffer<RGBQUAD>* fb) {
+    return rt_image{reinterpret_cast<uint8_t*>(fb->getData()), nullptr, static_cast<int32_t>(fb->getWidth()), static_cast<int32_t>(fb->getHeight()), 0};
+}
+// Accumulates flat records; materials are shared by pointer identity so that two elements with one material object
+// reference one rt_material (the reference shares materials through shared_ptr, 04 Main.cpp:181-199).
+struct Flat {
+    std::vector<rt_prim> prims; std::vector<rt_material> mats; std::vector<const void*> mat_keys; std::vector<rt_light> lights;
+    int32_t material(const void* key, const rt_material& m) {
+        if (key) for (size_t i = 0; i < mat_keys.size(); ++i) if (mat_keys[i] == key) return static_cast<int32_t>(i);
+        mats.push_back(m); mat_keys.push_back(key);
+        return static_cast<int32_t>(mats.size() - 1);
+    }
+    rt_scene scene() const {
+        return rt_scene{prims.data(), static_cast<int32_t>(prims.size()), mats.data(), static_cast<int32_t>(mats.size()), lights.data(), static_cast<int32_t>(lights.size())};
+    }
+};
+} // namespace rtbackend
