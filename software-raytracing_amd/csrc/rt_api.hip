@@ -70,6 +70,8 @@ void rotation_mat(const float deg[3], float out[9]) {
 struct HostScene {
     std::vector<int4> runs, info;
     std::vector<float4> geom, mats, lights;
+    std::vector<float4> slots;            // path scenes (variant 3/4): the slot section of rt_device.h
+    std::vector<size_t> slot_mat_fixups;  // indices into slots of the B records; B.w holds the material index until upload
     int has_aa = 0;
 };
 
@@ -116,25 +118,66 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         int gi = (int)H.geom.size();
         int dtype = P.type;
         const float* f = P.f;
-        switch (P.type) {
-        case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], variant == 0 ? f[3] : f[3] * f[3])); break;
-        case RT_PRIM_PLANE:
-            if (variant == 0) { H.geom.push_back(f4(f[3], f[4], f[5], 0)); H.geom.push_back(f4(f[0], f[1], f[2], 0)); }   // strict form: n, p0
-            else {
+        if (variant != 0) {   // path scenes: slot layout (rt_device.h)
+            float4 G = f4(0, 0, 0, 0), A = f4(0, 0, 0, 0), B = f4(0, 0, 0, 0), C = f4(0, 0, 0, 0), G1 = G, G2 = G, G3 = G;
+            bool wide = false;
+            switch (P.type) {
+            case RT_PRIM_SPHERE: {
+                G = f4(f[0], f[1], f[2], f[3] * f[3]);
+                float k = 1.0f / f[3];
+                A = f4(f[0], f[1], f[2], (P.flags & RT_PRIM_FLAG_FLIP_NORMALS) ? -k : k);
+                break; }
+            case RT_PRIM_PLANE: {
                 int axis = -1;    // unit normal exactly +-e_axis: shares 1/d per ray (bit-identical to the general form)
                 for (int a = 0; a < 3; ++a)
                     if (fabsf(f[3 + a]) == 1.0f && f[3 + (a + 1) % 3] == 0.0f && f[3 + (a + 2) % 3] == 0.0f) axis = a;
-                if (axis >= 0) { H.geom.push_back(f4(f[axis], f[3 + axis], 0, 0)); dtype = PRIM_AAPLANE_X + axis; H.has_aa = 1; }
-                else H.geom.push_back(f4(f[3], f[4], f[5], f[3] * f[0] + f[4] * f[1] + f[5] * f[2]));
+                if (axis >= 0) { G = f4(f[axis], 0, 0, 0); dtype = PRIM_AAPLANE_X + axis; H.has_aa = 1; }
+                else G = f4(f[3], f[4], f[5], f[3] * f[0] + f[4] * f[1] + f[5] * f[2]);
+                B = f4(f[3], f[4], f[5], 0); C = B;
+                break; }
+            case RT_PRIM_RECT: {
+                float neg[3] = {-f[5], -f[6], -f[7]}, pos[3] = {f[5], f[6], f[7]}, ri[9], rf[9];
+                rotation_mat(neg, ri); rotation_mat(pos, rf);                                           // Rectangle.hpp:58, :92
+                auto dotc = [&](int row) { return ri[3 * row] * f[0] + ri[3 * row + 1] * f[1] + ri[3 * row + 2] * f[2]; };
+                G = f4(ri[6], ri[7], ri[8], dotc(2));
+                G1 = f4(ri[0], ri[1], ri[2], -dotc(0)); G2 = f4(ri[3], ri[4], ri[5], -dotc(1)); G3 = f4(f[3] / 2.0f, f[4] / 2.0f, 0, 0);
+                B = f4(rf[2], rf[5], rf[8], 0); C = f4(ri[6], ri[7], ri[8], 0);
+                wide = true;
+                break; }
+            case RT_PRIM_TRIANGLE: {
+                float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
+                float n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};   // cross(e2,e1), Ray.hpp:159
+                float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                for (float& v : n) v = len > 0 ? v / len : 0.0f;
+                // Inverse of the matrix with COLUMNS e2, e1, n (Ray.hpp:190, Math.hpp:635-654); rows 0 and 1 are needed
+                float m[9] = {e2[0], e1[0], n[0], e2[1], e1[1], n[1], e2[2], e1[2], n[2]};
+                float det = m[0] * m[4] * m[8] + m[1] * m[5] * m[6] + m[2] * m[3] * m[7] - m[2] * m[4] * m[6] - m[0] * m[5] * m[7] - m[1] * m[3] * m[8];
+                float di = det != 0 ? 1 / det : 0.0f;
+                float r0[3] = {(m[4] * m[8] - m[7] * m[5]) * di, (m[2] * m[7] - m[1] * m[8]) * di, (m[1] * m[5] - m[2] * m[4]) * di};
+                float r1[3] = {(m[5] * m[6] - m[3] * m[8]) * di, (m[0] * m[8] - m[2] * m[6]) * di, (m[3] * m[2] - m[0] * m[5]) * di};
+                G = f4(n[0], n[1], n[2], n[0] * f[0] + n[1] * f[1] + n[2] * f[2]);
+                G1 = f4(r0[0], r0[1], r0[2], -(r0[0] * f[0] + r0[1] * f[1] + r0[2] * f[2]));
+                G2 = f4(r1[0], r1[1], r1[2], -(r1[0] * f[0] + r1[1] * f[1] + r1[2] * f[2]));
+                if (det == 0) G1 = f4(0, 0, 0, -1.0f);   // degenerate: Inverse returns zeros and (0,0) passes in the reference; keep it out here
+                B = f4(n[0], n[1], n[2], 0); C = B;
+                wide = true;
+                break; }
+            default: return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": unknown type " + std::to_string(P.type));
             }
-            break;
-        case RT_PRIM_RECT: {
-            if (variant == 0) return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles exist only in the path-tracing examples");
-            float neg[3] = {-f[5], -f[6], -f[7]}, pos[3] = {f[5], f[6], f[7]}, ri[9], rf[9];
-            rotation_mat(neg, ri); rotation_mat(pos, rf);                                               // Rectangle.hpp:58, :92
-            H.geom.push_back(f4(ri[0], ri[1], ri[2], f[0])); H.geom.push_back(f4(ri[3], ri[4], ri[5], f[1])); H.geom.push_back(f4(ri[6], ri[7], ri[8], f[2]));
-            H.geom.push_back(f4(f[3] / 2.0f, f[4] / 2.0f, rf[2], rf[5])); H.geom.push_back(f4(rf[8], 0, 0, 0));
-            break; }
+            B.w = __builtin_bit_cast(float, mat);
+            H.slots.push_back(G); H.slots.push_back(A); H.slot_mat_fixups.push_back(H.slots.size()); H.slots.push_back(B); H.slots.push_back(C);
+            if (wide) { H.slots.push_back(G1); H.slots.push_back(G2); H.slots.push_back(G3); H.slots.push_back(f4(0, 0, 0, 0)); }
+            // rectangles and triangles share one loop in the kernel but not one run: the run type picks the inside test
+            if (!H.runs.empty() && H.runs.back().x == dtype) H.runs.back().z++;
+            else H.runs.push_back(make_int4(dtype, 0, 1, i));
+            H.info.push_back(make_int4(dtype, 0, mat, (int)P.flags));
+            continue;
+        }
+        switch (P.type) {
+        // Whitted scenes (01/02): the IEEE-exact layout of rt_strict.h
+        case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], f[3])); break;
+        case RT_PRIM_PLANE: H.geom.push_back(f4(f[3], f[4], f[5], 0)); H.geom.push_back(f4(f[0], f[1], f[2], 0)); break;   // n, p0
+        case RT_PRIM_RECT: return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles exist only in the path-tracing examples");
         case RT_PRIM_TRIANGLE: {
             float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
             float n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};   // cross(e2,e1), Ray.hpp:159
@@ -166,8 +209,10 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
 // Packs the HostScene into one pinned blob, uploads it and fills DevScene with device pointers.
 int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
-    size_t o_runs = 0, o_geom = pad(o_runs + H.runs.size() * 16), o_info = pad(o_geom + H.geom.size() * 16),
-           o_mats = pad(o_info + H.info.size() * 16), o_lights = pad(o_mats + H.mats.size() * 16), total = pad(o_lights + H.lights.size() * 16 + 16);
+    // one spare zero record after the runs: the path kernels prefetch runs[r + 1]
+    size_t o_runs = 0, o_geom = pad(o_runs + (H.runs.size() + 1) * 16), o_info = pad(o_geom + H.geom.size() * 16),
+           o_slots = pad(o_info + (H.slots.empty() ? H.info.size() : 0) * 16), o_mats = pad(o_slots + H.slots.size() * 16),
+           o_lights = pad(o_mats + H.mats.size() * 16), total = pad(o_lights + H.lights.size() * 16 + 16);
     if (total > c->h_stage_cap) {
         if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
         c->h_stage = nullptr; c->h_stage_cap = 0;
@@ -178,15 +223,23 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     // the staging blob may still be in flight from the previous call on this stream
     HIPCHK(c, hipStreamSynchronize(st));
     char* h = (char*)c->h_stage;
+    memset(h, 0, o_geom);
     memcpy(h + o_runs, H.runs.data(), H.runs.size() * 16); memcpy(h + o_geom, H.geom.data(), H.geom.size() * 16);
-    memcpy(h + o_info, H.info.data(), H.info.size() * 16); memcpy(h + o_mats, H.mats.data(), H.mats.size() * 16);
+    if (H.slots.empty()) memcpy(h + o_info, H.info.data(), H.info.size() * 16);
+    memcpy(h + o_slots, H.slots.data(), H.slots.size() * 16);
+    for (size_t b : H.slot_mat_fixups) {   // material index -> byte offset of its record in the blob
+        float4* B = reinterpret_cast<float4*>(h + o_slots) + b;
+        uint32_t off = (uint32_t)(o_mats + (size_t)__builtin_bit_cast(int, B->w) * 48);
+        B->w = __builtin_bit_cast(float, off);
+    }
+    memcpy(h + o_mats, H.mats.data(), H.mats.size() * 16);
     memcpy(h + o_lights, H.lights.data(), H.lights.size() * 16);
     HIPCHK(c, hipMemcpyAsync(c->scene_buf.p, h, total, hipMemcpyHostToDevice, st));
     D.blob = (const float4*)c->scene_buf.p;
     D.off_runs = (int)(o_runs / 16); D.off_geom = (int)(o_geom / 16); D.off_info = (int)(o_info / 16);
     D.off_mats = (int)(o_mats / 16); D.off_lights = (int)(o_lights / 16); D.total_f4 = (int)(total / 16);
     D.n_runs = (int)H.runs.size(); D.n_prims = (int)H.info.size(); D.n_mats = (int)H.mats.size() / 3; D.n_lights = (int)H.lights.size() / 2;
-    D.has_aa = H.has_aa;
+    D.has_aa = H.has_aa; D.off_slots = (int)(o_slots / 16);
     return RT_OK;
 }
 

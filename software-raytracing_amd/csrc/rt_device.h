@@ -28,7 +28,8 @@ struct DevScene {
     const float4* __restrict__ blob;
     int off_runs, off_geom, off_info, off_mats, off_lights, total_f4;
     int n_runs, n_prims, n_mats, n_lights;
-    int has_aa;     // any axis-aligned plane run (then 1/d is computed once per ray)
+    int has_aa;     // any axis-aligned plane run
+    int off_slots;  // path scenes: float4 offset of the slot section (see "slot layout" below); geom/info unused there
 };
 
 // Section pointers over either the global blob (wave-uniform reads become scalar loads) or its LDS copy
@@ -105,80 +106,119 @@ __device__ __forceinline__ void rng_pair(uint32_t skey, uint32_t ctr, float& a, 
     b = (float)(r >> 16) * (1.0f / 65536.0f);
 }
 
-// ---- ray / primitive tests (fast forms, path tracing kernels) ----------------------------------------
-// Ray::intersectsSphere (Common/Ray.hpp:94-137) with a = d.d = 1 (every traced direction is unit); g = (c, r*r).
-// Roots t1 <= t2; "a root below tMin becomes tMax" (:127-128): a ray that starts inside a sphere whose far root
-// lies beyond tMax still reports a hit AT tMax (:129-134).  disc < 0 gives NaN roots, which fail every compare.
-__device__ __forceinline__ bool hit_sphere(float4 g, f3 o, f3 d, float tmin, float tmax, float& t) {
-    f3 co = F3(g) - o;
-    float b = dot(d, co);
-    float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, -g.w)));
-    float s = sqrt_fast(fmaf(b, b, -c));
-    float t1 = b - s, t2 = b + s;
-    bool near_behind = t1 < tmin;
-    float tc = near_behind ? t2 : t1;
-    t = fminf(tc, tmax);
-    return (tc >= tmin) & (near_behind | (tc <= tmax));
-}
-// Ray::intersectsPlane (Ray.hpp:223-249); g = (n, n.p0).  dot==0 gives inf/NaN, which fails the range test.
-// tminp = max(tMin, smallest positive float) folds the reference's "t > 0 && t >= tMin" into one compare.
-__device__ __forceinline__ bool hit_plane(float4 g, f3 o, f3 d, float tminp, float tmax, float& t) {
-    f3 n = F3(g);
-    t = (g.w - dot(n, o)) * rcp_fast(dot(d, n));
-    return (t >= tminp) & (t <= tmax);
-}
-// The same for a plane whose normal is +-e_axis: n.p0 - n.o = +-(p0_a - o_a), d.n = +-d_a, so
-// t = (p0_a - o_a) * (1/d_a) with 1/d shared by all such planes of a ray; bit-identical to hit_plane.
-__device__ __forceinline__ bool hit_aaplane(float p0a, float oa, float inv_da, float tminp, float tmax, float& t) {
-    t = (p0a - oa) * inv_da;
-    return (t >= tminp) & (t <= tmax);
-}
-// scene::Rectangle::intersectsRay (04 Scene/Rectangle.hpp:51-97) over Ray::intersectsAARectangleXy
-// (Ray.hpp:263-283): ray into object space by R(-orient), z=0 plane, inclusive |x|<=hw, |y|<=hh.
-__device__ __forceinline__ bool hit_rect(const float4* g, f3 o, f3 d, float tminp, float tmax, float& t) {
-    float4 r0 = g[0], r1 = g[1], r2 = g[2], r3 = g[3];
-    f3 oc = o - F3(r0.w, r1.w, r2.w);
-    float oz = dot(F3(r2), oc), dz = dot(F3(r2), d);
-    t = -oz * rcp_fast(dz);
-    float x = fmaf(dot(F3(r0), d), t, dot(F3(r0), oc));
-    float y = fmaf(dot(F3(r1), d), t, dot(F3(r1), oc));
-    return (t >= tminp) & (t <= tmax) & (fabsf(x) <= r3.x) & (fabsf(y) <= r3.y);
-}
-// Ray::intersectsTriangle (Ray.hpp:150-212): plane hit, then coordinates in the [e2 e1 n] basis,
-// inclusive x>=0, y>=0, x+y<=1.
-__device__ __forceinline__ bool hit_tri(const float4* g, f3 o, f3 d, float tminp, float tmax, float& t) {
-    float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-    f3 n = F3(g0);
-    t = (g0.w - dot(n, o)) * rcp_fast(dot(d, n));
-    f3 pt = madd(d, t, o) - F3(g1);
-    float x = dot(F3(g2), pt), y = dot(F3(g3), pt);
-    return (t >= tminp) & (t <= tmax) & (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);
-}
+// ---- path-tracing scenes: slot layout ---------------------------------------------------------------
+// The path kernels (03/04) read a second section of the blob, 'slots': the primitives IN SCENE ORDER (order
+// matters: exact ties and the sphere tMax rule depend on it), each a fixed number of float4 per device type,
+//   [G | A | B | C]            sphere, plane, axis-aligned plane      (4 float4 = 64 bytes)
+//   [G | A | B | C | G1 G2 G3 -] rectangle, triangle                   (8 float4 = 128 bytes)
+// G..G3 feed the ray test, A,B,C feed shading and sit at the same offsets for every type, so the closest-hit
+// loop only has to remember WHERE the winner is (its byte offset in the blob), not what it is:
+//   A = (c.xyz, k)   B = (m.xyz, byte offset of the material record)   C = (f.xyz, 0)
+//   normal n = (p - c)*k + m, facing vector (p - c)*k + f; the hit is a back face when dot(d, facing) > 0.
+//     sphere: c = centre, k = +-1/r ('inverted' negates), m = f = 0      (03 Sphere.hpp:57-73, 04 Scene/Sphere.hpp:58-74)
+//     planes, triangle: c = 0, k = 0, m = f = unit normal               (04 Scene/Plane.hpp:55-66)
+//     rectangle: m = GetRotationMat(orientation)*(0,0,1), f = row 2 of GetRotationMat(-orientation): the reference
+//                decides the side in object space and rotates the normal out with the OTHER matrix (Rectangle.hpp:58-92)
+//   G: sphere (c, r*r) | plane (n, n.p0) | aaplane (p0[axis],-,-,-)
+//      rectangle G=(z, z.c) G1=(x, -x.c) G2=(y, -y.c) G3=(hw, hh, -, -) with x,y,z the rows of GetRotationMat(-orientation)
+//      triangle  G=(n, n.v0) G1=(i0, -i0.v0) G2=(i1, -i1.v0), n = normalize(cross(e2,e1)), i = rows 0,1 of Inverse([e2 e1 n])
+// runs (int4 {device type, -, count, -} per maximal run of one type) are read with scalar loads from the GLOBAL blob
+// even when the slots are staged in LDS: they steer uniform control flow, which wants SGPRs, while primitive
+// operands want VGPRs (an SGPR operand halves VALU issue rate on gfx950, profiles/r01_valu_issue_rates_ubench.txt).
+enum { SLOT_BYTES = 64, SLOT_A = 16, SLOT_B = 32, SLOT_C = 48, SLOT_G1 = 64, SLOT_G2 = 80, SLOT_G3 = 96 };
+
+// Scene memory: either the global blob (base pointer + byte offset; uniform offsets become scalar loads) or its LDS
+// copy, where an "offset" IS the 32-bit LDS address (the staging base is folded in once, not added per read).
+#define RT_LDS_AS __attribute__((address_space(3)))
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool LDS> struct SceneMem {
+    const char* base;
+    __device__ __forceinline__ float4 ld4(uint32_t off) const {
+        if (LDS) { v4f v = *(const RT_LDS_AS v4f*)(uintptr_t)off; return make_float4(v.x, v.y, v.z, v.w); }
+        return *reinterpret_cast<const float4*>(base + off);
+    }
+    __device__ __forceinline__ float ld1(uint32_t off) const {
+        if (LDS) return *(const RT_LDS_AS float*)(uintptr_t)off;
+        return *reinterpret_cast<const float*>(base + off);
+    }
+    // blob byte offset -> what ld4/ld1 take
+    __device__ __forceinline__ uint32_t at(uint32_t blob_off) const {
+        if (LDS) return (uint32_t)(uintptr_t)(const RT_LDS_AS char*)base + blob_off;
+        return blob_off;
+    }
+};
 
 // Closest hit, 03 Scene::intersectsRay / 04 scene::List::intersectsRay (03 Utils.h:255-271, 04 Utils.h:362-390):
 // tMax shrinks to the closest hit so far and a test accepts t <= tMax, so the LAST element wins exact ties.
-__device__ __forceinline__ int closest_hit_shrinking(const Scn& S, bool has_aa, f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {
-    int best = -1;
+// q = SceneMem address of the first slot.  Returns the address of the winning slot (0 = miss: address 0 is the runs
+// section, or the first bytes of LDS, never a slot).
+// All traced directions are unit vectors (Ray's constructor normalises), so a = d.d = 1 in the sphere test.
+template <bool LDS>
+__device__ __forceinline__ uint32_t closest_hit_slots(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
+                                                      f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {
+    uint32_t best = 0U;
     float closest = tmax;
-    f3 inv_d = F3(0, 0, 0);
-    if (has_aa) inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
-    for (int r = 0; r < S.n_runs; ++r) {
-        int4 run = S.runs[r];
-        const float4* g = S.geom + run.y;
-        if (run.x == PRIM_SPHERE) {
-            for (int i = 0; i < run.z; ++i) { float t; if (hit_sphere(g[i], o, d, tmin, closest, t)) { closest = t; best = run.w + i; } }
-        } else if (run.x == PRIM_AAPLANE_X) {
-            for (int i = 0; i < run.z; ++i) { float t; if (hit_aaplane(g[i].x, o.x, inv_d.x, tminp, closest, t)) { closest = t; best = run.w + i; } }
-        } else if (run.x == PRIM_AAPLANE_Y) {
-            for (int i = 0; i < run.z; ++i) { float t; if (hit_aaplane(g[i].x, o.y, inv_d.y, tminp, closest, t)) { closest = t; best = run.w + i; } }
-        } else if (run.x == PRIM_AAPLANE_Z) {
-            for (int i = 0; i < run.z; ++i) { float t; if (hit_aaplane(g[i].x, o.z, inv_d.z, tminp, closest, t)) { closest = t; best = run.w + i; } }
-        } else if (run.x == PRIM_PLANE) {
-            for (int i = 0; i < run.z; ++i) { float t; if (hit_plane(g[i], o, d, tminp, closest, t)) { closest = t; best = run.w + i; } }
-        } else if (run.x == PRIM_RECT) {
-            for (int i = 0; i < run.z; ++i) { float t; if (hit_rect(g + 5 * i, o, d, tminp, closest, t)) { closest = t; best = run.w + i; } }
+    // LDS addresses are VGPR operands of ds_read anyway: keep the cursor in a VGPR (one v_add per primitive) instead of
+    // letting the compiler hold it in an SGPR and copy it out twice per primitive; global reads want it uniform (scalar loads)
+    if (LDS) asm volatile("" : "+v"(q));
+    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
+    int4 run = runs[0];
+    for (int r = 0; r < n_runs; ++r) {
+        const int type = run.x, count = run.z;
+        run = runs[r + 1];     // prefetch (the section is padded by one record)
+        if (type == PRIM_SPHERE) {
+            // Ray::intersectsSphere (Common/Ray.hpp:94-137).  Roots t1 <= t2; "a root below tMin becomes tMax" (:127-128):
+            // a ray that starts inside a sphere whose far root lies beyond tMax still reports a hit AT tMax (:129-134):
+            // the element wins, the distance stays.  disc < 0 gives NaN roots, which fail every compare.
+            for (int i = 0; i < count; ++i, q += SLOT_BYTES) {
+                float4 g = M.ld4(q);
+                f3 co = F3(g) - o;
+                float b = dot(d, co);
+                float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, -g.w)));
+                float s = sqrt_fast(fmaf(b, b, -c));
+                float t1 = b - s, t2 = b + s;
+                bool near_behind = t1 < tmin;
+                float tc = near_behind ? t2 : t1;
+                bool ge = tc >= tmin, le = tc <= closest;
+                closest = (ge & le) ? tc : closest;
+                best = (ge & (near_behind | le)) ? q : best;
+            }
+        } else if (type >= PRIM_AAPLANE_X) {
+            // Ray::intersectsPlane (Ray.hpp:223-249) for a normal +-e_axis: n.p0 - n.o = +-(p0_a - o_a), d.n = +-d_a, so
+            // t = (p0_a - o_a) * (1/d_a), 1/d shared by all such planes of the ray.  tminp = max(tMin, smallest positive
+            // float) folds "t > 0 && t >= tMin" into one compare; d_a = 0 gives inf/NaN, which fails the range test.
+#define RT_AA_LOOP(OA, IA) for (int i = 0; i < count; ++i, q += SLOT_BYTES) { \
+                float t = (M.ld1(q) - (OA)) * (IA); bool hit = (t >= tminp) & (t <= closest); \
+                closest = hit ? t : closest; best = hit ? q : best; }
+            if (type == PRIM_AAPLANE_X) RT_AA_LOOP(o.x, inv_d.x)
+            else if (type == PRIM_AAPLANE_Y) RT_AA_LOOP(o.y, inv_d.y)
+            else RT_AA_LOOP(o.z, inv_d.z)
+#undef RT_AA_LOOP
+        } else if (type == PRIM_PLANE) {
+            for (int i = 0; i < count; ++i, q += SLOT_BYTES) {
+                float4 g = M.ld4(q);
+                float t = (g.w - dot(F3(g), o)) * rcp_fast(dot(F3(g), d));
+                bool hit = (t >= tminp) & (t <= closest);
+                closest = hit ? t : closest; best = hit ? q : best;
+            }
         } else {
-            for (int i = 0; i < run.z; ++i) { float t; if (hit_tri(g + 4 * i, o, d, tminp, closest, t)) { closest = t; best = run.w + i; } }
+            // scene::Rectangle::intersectsRay (04 Scene/Rectangle.hpp:51-97, Ray.hpp:263-283): plane z' = 0 of the object
+            // frame, then inclusive |x'| <= hw, |y'| <= hh.  Ray::intersectsTriangle (Ray.hpp:150-212): plane hit, then
+            // coordinates in the [e2 e1 n] basis, inclusive x >= 0, y >= 0, x + y <= 1.  Both evaluate the in-plane
+            // coordinates at the hit point p = o + t*d with the constant offset folded into the row's w.
+            const bool rect = type == PRIM_RECT;
+            for (int i = 0; i < count; ++i, q += 2 * SLOT_BYTES) {
+                float4 g = M.ld4(q), g1 = M.ld4(q + SLOT_G1), g2 = M.ld4(q + SLOT_G2);
+                float t = (g.w - dot(F3(g), o)) * rcp_fast(dot(F3(g), d));
+                f3 p = madd(d, t, o);
+                float x = fmaf(g1.z, p.z, fmaf(g1.y, p.y, fmaf(g1.x, p.x, g1.w)));
+                float y = fmaf(g2.z, p.z, fmaf(g2.y, p.y, fmaf(g2.x, p.x, g2.w)));
+                bool in;
+                if (rect) { float4 g3 = M.ld4(q + SLOT_G3); in = (fabsf(x) <= g3.x) & (fabsf(y) <= g3.y); }
+                else      in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);
+                bool hit = (t >= tminp) & (t <= closest) & in;
+                closest = hit ? t : closest; best = hit ? q : best;
+            }
         }
     }
     t_out = closest;

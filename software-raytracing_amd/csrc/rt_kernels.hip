@@ -16,13 +16,15 @@ namespace rt {
 template <int VARIANT, bool LDS>
 __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 smem[];
-    const float4* base = SD.blob;
+    const char* base = reinterpret_cast<const char*>(SD.blob);
     if (LDS) {   // stage the whole flattened scene in LDS: primitive operands then arrive in VGPRs (ds_read), not SGPRs
         for (int i = threadIdx.x; i < SD.total_f4; i += 256) smem[i] = SD.blob[i];
         __syncthreads();
-        base = smem;
+        base = reinterpret_cast<const char*>(smem);
     }
-    const Scn S = scn_over(SD, base);
+    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_runs);   // always global: scalar loads
+    const SceneMem<LDS> M{base};
+    const uint32_t slots0 = M.at((uint32_t)SD.off_slots * 16U), mats0 = M.at(0U);
     int px, py;
     bool inside = pixel_of_thread(A.width, A.height, px, py);
     const int slice = blockIdx.y;
@@ -63,36 +65,27 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
             // TraceTay: one scene query (03 Main.cpp:392, 04 Main.cpp:447)
             ++rays;
             float t;
-            int idx = closest_hit_shrinking(S, SD.has_aa != 0, o, d, A.t_min, A.t_min_pos, A.t_max, t);
-            if (idx < 0) {
+            uint32_t hit = closest_hit_slots<LDS>(M, runs, SD.n_runs, slots0, o, d, A.t_min, A.t_min_pos, A.t_max, t);
+            if (hit == 0U) {
                 if (VARIANT == 3) {   // sky: Mix(white, (0.5,0.7,1), 0.5*(d.y+1)) (03 Main.cpp:430-432)
                     float h = 0.5f * (d.y + 1.0f);
                     acc = acc + thr * F3(fmaf(-0.5f, h, 1.0f), fmaf(-0.3f, h, 1.0f), 1.0f);
                 }
                 alive = false;
             } else {
-                int4 inf = S.info[idx];
+                // hit record (03 Sphere.hpp:57-73; 04 Scene/Sphere.hpp:58-74, Plane.hpp:55-66, Rectangle.hpp:79-92), one
+                // formula for every primitive type (slot layout, rt_device.h): n = (p - c)*k + m, turned against the ray
+                float4 sa = M.ld4(hit + SLOT_A), sb = M.ld4(hit + SLOT_B), sc = M.ld4(hit + SLOT_C);
                 f3 p = madd(d, t, o);
-                f3 n;
-                bool back;
-                if (inf.x == PRIM_SPHERE) {          // 03 Sphere.hpp:57-73, 04 Scene/Sphere.hpp:58-74
-                    n = normalize(p - F3(S.geom[inf.y]));
-                    if (inf.w & 1) n = -n;
-                    back = dot(d, n) > 0.0f;
-                } else if (inf.x == PRIM_RECT) {     // 04 Scene/Rectangle.hpp:79-92
-                    float4 r2 = S.geom[inf.y + 2], r3 = S.geom[inf.y + 3], r4 = S.geom[inf.y + 4];
-                    n = F3(r3.z, r3.w, r4.x);
-                    back = dot(F3(r2), d) > 0.0f;
-                } else if (inf.x >= PRIM_AAPLANE_X) { // plane with normal +-e_axis (04 Scene/Plane.hpp:55-66)
-                    float sgn = S.geom[inf.y].y;
-                    n = F3(inf.x == PRIM_AAPLANE_X ? sgn : 0.0f, inf.x == PRIM_AAPLANE_Y ? sgn : 0.0f, inf.x == PRIM_AAPLANE_Z ? sgn : 0.0f);
-                    back = dot(d, n) > 0.0f;
-                } else {                             // plane 04 Scene/Plane.hpp:55-66; triangle likewise
-                    n = F3(S.geom[inf.y]);
-                    back = dot(d, n) > 0.0f;
-                }
-                if (back) n = -n;
-                float4 m0 = S.mats[inf.z * 3], m2 = S.mats[inf.z * 3 + 2];
+                f3 pc = p - F3(sa);
+                f3 n = madd(pc, sa.w, F3(sb));
+                float facing = dot(d, madd(pc, sa.w, F3(sc)));
+                bool back = facing > 0.0f;
+                // n = back ? -n : n through the sign bit of (0 - facing): set exactly when facing > 0
+                uint32_t flip = __float_as_uint(0.0f - facing) & 0x80000000U;
+                n = F3(__uint_as_float(__float_as_uint(n.x) ^ flip), __uint_as_float(__float_as_uint(n.y) ^ flip), __uint_as_float(__float_as_uint(n.z) ^ flip));
+                const uint32_t moff = mats0 + __float_as_uint(sb.w);
+                float4 m0 = M.ld4(moff), m2 = M.ld4(moff + 32U);
                 int mtype = __float_as_int(m0.w);
                 if (mtype == MAT_DIFFUSE || mtype == MAT_METAL) {
                     f3 axis = (mtype == MAT_METAL) ? reflect(d, n) : n;
