@@ -490,7 +490,8 @@ static float reflectance(v3 v, v3 n, float ratio) {
 
 /* Material::scatter of 03 (Materials.hpp:50-75,142-169,233-265) and materials::*::scatteredRay of
  * 04 (Diffuse.hpp:64-82, Metal.hpp:67-88, Refractive.hpp:80-104).  Returns the scattered ray and
- * attenuation.  RNG counters at recursion depth k: draw 4(k+1) gives the pair (fi, theta/height), draw 4(k+1)+2 the Schlick threshold. */
+ * attenuation.  RNG: ONE draw per bounce, counter 4(k+1) at recursion depth k: its 16-bit halves are the pair (fi, theta/height)
+ * of the hemisphere/cone samplers, its top 24 bits the dielectric's reflect-or-refract threshold (only one of the two is used). */
 static ray_t scatter(const pctx_t* pc, const rt_material* m, const ray_t* in, const hit_t* h, int depth, v3* att) {
     uint32_t c0 = 4U * ((uint32_t)depth + 1U);
     float ua, ub;
@@ -526,7 +527,7 @@ static ray_t scatter(const pctx_t* pc, const rt_material* m, const ray_t* in, co
     case RT_MAT_DIELECTRIC: {
         float idx = h->front ? m->refraction_index : 1.0f / m->refraction_index;
         dir = reflect3(in->d, h->normal);
-        if (reflectance(in->d, h->normal, 1.0f / idx) < rng_u01(pc->sample_key, c0 + 2))
+        if (reflectance(in->d, h->normal, 1.0f / idx) < rng_u01(pc->sample_key, c0))
             dir = refract3(in->d, h->normal, idx, 1);
         *att = V(1.0f, 1.0f, 1.0f);
         return make_ray(h->point, dir);

@@ -99,6 +99,7 @@ __device__ __forceinline__ float rng_u01(uint32_t skey, uint32_t ctr) {
     return (float)(r >> 8) * (1.0f / 16777216.0f);
 }
 
+__device__ __forceinline__ uint32_t rng_bits(uint32_t skey, uint32_t ctr) { return lowbias32(skey + (ctr + 1U) * 0x9E3779B9U); }
 // two 16-bit uniforms from ONE draw: a = low half, b = high half, each k/65536
 __device__ __forceinline__ void rng_pair(uint32_t skey, uint32_t ctr, float& a, float& b) {
     uint32_t r = lowbias32(skey + (ctr + 1U) * 0x9E3779B9U);
@@ -166,6 +167,7 @@ __device__ __forceinline__ uint32_t closest_hit_slots(const SceneMem<LDS> M, con
     for (int r = 0; r < n_runs; ++r) {
         const int type = run.x, count = run.z;
         run = runs[r + 1];     // prefetch (the section is padded by one record)
+        if (LDS) asm volatile("" : "+v"(q), "+v"(best), "+v"(closest));   // one definition point per run for the carried values
         if (type == PRIM_SPHERE) {
             // Ray::intersectsSphere (Common/Ray.hpp:94-137).  Roots t1 <= t2; "a root below tMin becomes tMax" (:127-128):
             // a ray that starts inside a sphere whose far root lies beyond tMax still reports a hit AT tMax (:129-134):

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
 
     for (;;) {
         bool want = !alive && s_next < s_end;
-        unsigned long long m_want = __ballot(want), m_alive = __ballot(alive);
+        unsigned long long m_want = __builtin_amdgcn_ballot_w64(want), m_alive = __builtin_amdgcn_ballot_w64(alive);
         if ((m_want | m_alive) == 0ULL) break;
         if (m_want && (m_alive == 0ULL || __popcll(m_want) >= A.regen_threshold)) {
             if (want) {   // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369)
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
                 // hit record (03 Sphere.hpp:57-73; 04 Scene/Sphere.hpp:58-74, Plane.hpp:55-66, Rectangle.hpp:79-92), one
                 // formula for every primitive type (slot layout, rt_device.h): n = (p - c)*k + m, turned against the ray
                 float4 sa = M.ld4(hit + SLOT_A), sb = M.ld4(hit + SLOT_B), sc = M.ld4(hit + SLOT_C);
-                f3 p = madd(d, t, o);
-                f3 pc = p - F3(sa);
+                o = madd(d, t, o);                       // the hit point is the next origin; nothing below needs the old one
+                f3 pc = o - F3(sa);
                 f3 n = madd(pc, sa.w, F3(sb));
                 float facing = dot(d, madd(pc, sa.w, F3(sc)));
                 bool back = facing > 0.0f;
@@ -87,50 +87,56 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
                 const uint32_t moff = mats0 + __float_as_uint(sb.w);
                 float4 m0 = M.ld4(moff), m2 = M.ld4(moff + 32U);
                 int mtype = __float_as_int(m0.w);
-                if (mtype == MAT_DIFFUSE || mtype == MAT_METAL) {
-                    f3 axis = (mtype == MAT_METAL) ? reflect(d, n) : n;
-                    f3 nd = axis;
-                    if (m2.y >= 0.0f) {
-                        // RndHemisphereVec (03 Utils.h:64-88) / RndHemisphereVec3 (04 Utils.h:132-157)
-                        uint32_t c0 = 4U * ((uint32_t)depth + 1U);
-                        float u_fi, u_th;
-                        rng_pair(skey, c0, u_fi, u_th);
-                        // b = Normalize(Cross(dir, dir + 0.01)) = Normalize(Cross(dir, (1,1,1))): the 0.01 and dir x dir cancel;
-                        // c = Cross(dir, b) is already unit (dir, b orthonormal), so the reference's second Normalize is a no-op
-                        f3 b = F3(axis.y - axis.z, axis.z - axis.x, axis.x - axis.y);
-                        float bl2 = dot(b, b);
-                        bool degenerate = !(bl2 > 0.0f);
-                        b = b * (degenerate ? 0.0f : rsq_fast(bl2));
-                        f3 c = cross(axis, b);
-                        const float fi_rev = (float)((360.0 / 57.2958f) / 6.283185307179586);   // fi/(2*pi)
-                        float cf = __builtin_amdgcn_cosf(u_fi * fi_rev), sf = __builtin_amdgcn_sinf(u_fi * fi_rev);
-                        float ct, st;
-                        if (VARIANT == 3) {   // theta = U(-1,1)*thetaMax/57.2958
-                            float th_rev = (2.0f * u_th - 1.0f) * m2.y * 0.15915494309189535f;
-                            ct = __builtin_amdgcn_cosf(th_rev); st = __builtin_amdgcn_sinf(th_rev);
-                        } else {              // theta = acos(U(cos(thetaMax/57.2958), 1))
-                            ct = fmaf(1.0f - m2.y, u_th, m2.y);
-                            st = sqrt_fast(fmaxf(fmaf(-ct, ct, 1.0f), 0.0f));
+                if (mtype == MAT_DIFFUSE || mtype == MAT_METAL || mtype == MAT_DIELECTRIC) {
+                    // one draw per bounce serves whichever material was hit: (fi, theta) halves for the hemisphere/cone
+                    // samplers, the top 24 bits for the dielectric's reflect-or-refract choice
+                    const uint32_t r = rng_bits(skey, 4U * ((uint32_t)depth + 1U));
+                    const float dn = dot(d, n);
+                    const f3 refl = madd(n, -2.0f * dn, d);          // math::Reflect (Math.hpp:291-294)
+                    if (mtype == MAT_DIELECTRIC) {                   // 03 Materials.hpp:233-265, 04 Refractive.hpp:80-104
+                        float eta = back ? m0.x : m2.z;              // m0.x = 1/refractionIndex (host-precomputed)
+                        float q = 1.0f - fmaxf(-dn, 0.0f), q2 = q * q;
+                        float refl_p = fmaf(1.0f - m2.w, q2 * q2 * q, m2.w);
+                        float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+                        // math::Refract, reflect-on-TIR form (Math.hpp:306-312)
+                        float k = fmaf(-eta * eta, fmaf(-dn, dn, 1.0f), 1.0f);
+                        float s = fmaf(eta, dn, sqrt_fast(fmaxf(k, 0.0f)));
+                        f3 refr = madd(n, -s, d * eta);
+                        d = sel((refl_p < u) & !(k < 0.0f), refr, refl);
+                    } else {
+                        f3 axis = sel(mtype == MAT_METAL, refl, n);
+                        f3 nd = axis;
+                        if (m2.y >= 0.0f) {
+                            // RndHemisphereVec (03 Utils.h:64-88) / RndHemisphereVec3 (04 Utils.h:132-157)
+                            float u_fi = (float)(r & 0xFFFFU) * (1.0f / 65536.0f), u_th = (float)(r >> 16) * (1.0f / 65536.0f);
+                            // b = Normalize(Cross(dir, dir + 0.01)) = Normalize(Cross(dir, (1,1,1))): the 0.01 and dir x dir cancel;
+                            // c = Cross(dir, b) is already unit (dir, b orthonormal), so the reference's second Normalize is a no-op
+                            f3 b = F3(axis.y - axis.z, axis.z - axis.x, axis.x - axis.y);
+                            float bl2 = dot(b, b);
+                            bool degenerate = !(bl2 > 0.0f);
+                            b = b * (degenerate ? 0.0f : rsq_fast(bl2));
+                            f3 c = cross(axis, b);
+                            const float fi_rev = (float)((360.0 / 57.2958f) / 6.283185307179586);   // fi/(2*pi)
+                            float cf = __builtin_amdgcn_cosf(u_fi * fi_rev), sf = __builtin_amdgcn_sinf(u_fi * fi_rev);
+                            float ct, st;
+                            if (VARIANT == 3) {   // theta = U(-1,1)*thetaMax/57.2958
+                                float th_rev = (2.0f * u_th - 1.0f) * m2.y * 0.15915494309189535f;
+                                ct = __builtin_amdgcn_cosf(th_rev); st = __builtin_amdgcn_sinf(th_rev);
+                            } else {              // theta = acos(U(cos(thetaMax/57.2958), 1))
+                                ct = fmaf(1.0f - m2.y, u_th, m2.y);
+                                st = sqrt_fast(fmaf(-ct, ct, 1.0f));   // ct <= 1 exactly (u_th < 1), so the fused 1 - ct*ct is never negative
+                            }
+                            f3 ring = madd(c, sf, b * cf);
+                            nd = madd(ring, st, axis * ct);
+                            // Ray's constructor normalises (Common/Ray.hpp:33-34); nd is unit already unless the frame
+                            // collapsed (axis parallel to (1,1,1): Normalize(0) = 0), where it is axis*cos(theta).
+                            if (degenerate) nd = normalize(nd);
                         }
-                        f3 ring = madd(c, sf, b * cf);
-                        nd = madd(ring, st, axis * ct);
-                        // Ray's constructor normalises (Common/Ray.hpp:33-34); nd is unit already unless the frame
-                        // collapsed (axis parallel to (1,1,1): Normalize(0) = 0), where it is axis*cos(theta).
-                        if (degenerate) nd = normalize(nd);
+                        f3 att = F3(m0);
+                        if (VARIANT == 4) att = att * fmaxf(dot(nd, n), 0.0f);     // 04 Diffuse.hpp:77-78, Metal.hpp:83-84
+                        thr = thr * att;
+                        d = nd;
                     }
-                    f3 att = F3(m0);
-                    if (VARIANT == 4) att = att * fmaxf(dot(nd, n), 0.0f);     // 04 Diffuse.hpp:77-78, Metal.hpp:83-84
-                    thr = thr * att;
-                    d = nd; o = p;
-                    ++depth;
-                } else if (mtype == MAT_DIELECTRIC) {   // 03 Materials.hpp:233-265, 04 Refractive.hpp:80-104
-                    float idxr = back ? m0.x : m2.z;   // m0.x = 1/refractionIndex (host-precomputed)
-                    float cosine = fmaxf(-dot(d, n), 0.0f);
-                    float q = 1.0f - cosine, q2 = q * q;
-                    float refl_p = fmaf(1.0f - m2.w, q2 * q2 * q, m2.w);
-                    float u = rng_u01(skey, 4U * ((uint32_t)depth + 1U) + 2U);
-                    f3 nd = (refl_p < u) ? refract(d, n, idxr) : reflect(d, n);
-                    d = nd; o = p;
                     ++depth;
                 } else {
                     if (VARIANT == 4 && mtype == MAT_LIGHT && !back) acc = acc + thr * F3(m0);   // Light.hpp:47-54, Main.cpp:480-483

@@ -8,7 +8,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-LIB_PATH = os.path.join(_HERE, "librt_mi355.so")
+LIB_PATH = os.environ.get("RT_MI355_LIB") or os.path.join(_HERE, "librt_mi355.so")   # override: A/B builds in tools/
 _LIB = None
 
 
