@@ -577,8 +577,8 @@ static int trace_path(const pctx_t* pc, const ray_t* ray, v3* color, int depth) 
  * semantics are NOT used: overwritten), sumsq (optional): per-pixel sum of squared sample
  * luminance-free per-channel values (for variance estimates), bgra (optional, only meaningful
  * when the full sample range was rendered): gamma-2 + truncation as the reference. */
-int orc_render_path(const rt_scene* scene, const rt_camera* cam, const rt_path_params* prm,
-                    int width, int height, int y0, int y1, float* sum, float* sumsq, uint8_t* bgra, uint64_t* counts) {
+static int render_path_rows(const rt_scene* scene, const rt_camera* cam, const rt_path_params* prm,
+                            int width, int height, int y0, int y1, float* sum, float* sumsq, uint8_t* bgra, uint64_t* counts, uint32_t* px_rays) {
     if (!scene || !cam || !prm || width <= 0 || height <= 0) return RT_ERR_BAD_ARG;
     float w = (float)width, h = (float)height;
     float fov_rad = (float)(cam->fov_deg / (180.0f / ORC_PI));
@@ -593,6 +593,7 @@ int orc_render_path(const rt_scene* scene, const rt_camera* cam, const rt_path_p
             uint32_t pixel = (uint32_t)j * (uint32_t)width + (uint32_t)i;
             uint32_t pkey = rng_pixel_key(prm->seed, pixel);
             v3 pix = V(0, 0, 0), pix2 = V(0, 0, 0);
+            const uint64_t rays_before = cnt.rays;
             for (int s = s0; s < s1; s++) {
                 pc.sample_key = rng_sample_key(pkey, (uint32_t)s);
                 float bx = 0.5f, by = 0.5f;
@@ -607,6 +608,7 @@ int orc_render_path(const rt_scene* scene, const rt_camera* cam, const rt_path_p
                 pix2 = add(pix2, mulv(c, c));
             }
             size_t o = (size_t)pixel;
+            if (px_rays) px_rays[o] = (uint32_t)(cnt.rays - rays_before);
             if (sum) { sum[o * 3 + 0] = pix.x; sum[o * 3 + 1] = pix.y; sum[o * 3 + 2] = pix.z; }
             if (sumsq) { sumsq[o * 3 + 0] = pix2.x; sumsq[o * 3 + 1] = pix2.y; sumsq[o * 3 + 2] = pix2.z; }
             if (bgra) {
@@ -618,6 +620,16 @@ int orc_render_path(const rt_scene* scene, const rt_camera* cam, const rt_path_p
     }
     if (counts) { counts[0] += cnt.rays; counts[1] += cnt.shadow_rays; }
     return RT_OK;
+}
+
+int orc_render_path(const rt_scene* scene, const rt_camera* cam, const rt_path_params* prm,
+                    int width, int height, int y0, int y1, float* sum, float* sumsq, uint8_t* bgra, uint64_t* counts) {
+    return render_path_rows(scene, cam, prm, width, height, y0, y1, sum, sumsq, bgra, counts, NULL);
+}
+/* The same, also reporting the number of scene queries each pixel made (debugging aid for parity tests). */
+int orc_render_path_px(const rt_scene* scene, const rt_camera* cam, const rt_path_params* prm,
+                       int width, int height, int y0, int y1, float* sum, uint64_t* counts, uint32_t* px_rays) {
+    return render_path_rows(scene, cam, prm, width, height, y0, y1, sum, NULL, NULL, counts, px_rays);
 }
 
 /* The tail of Render (03 Main.cpp:352-367): sum/divisor, optional sqrt gamma, Clamp, truncation, B,G,R,255

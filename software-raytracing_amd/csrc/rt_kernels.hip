@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
                     const uint32_t r = rng_bits(skey, 4U * ((uint32_t)depth + 1U));
                     const float dn = dot(d, n);
                     const f3 refl = madd(n, -2.0f * dn, d);          // math::Reflect (Math.hpp:291-294)
+                    f3 nd;
                     if (mtype == MAT_DIELECTRIC) {                   // 03 Materials.hpp:233-265, 04 Refractive.hpp:80-104
                         float eta = back ? m0.x : m2.z;              // m0.x = 1/refractionIndex (host-precomputed)
                         float q = 1.0f - fmaxf(-dn, 0.0f), q2 = q * q;
@@ -102,19 +103,18 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
                         float k = fmaf(-eta * eta, fmaf(-dn, dn, 1.0f), 1.0f);
                         float s = fmaf(eta, dn, sqrt_fast(fmaxf(k, 0.0f)));
                         f3 refr = madd(n, -s, d * eta);
-                        d = sel((refl_p < u) & !(k < 0.0f), refr, refl);
+                        nd = sel((refl_p < u) & !(k < 0.0f), refr, refl);
                     } else {
                         f3 axis = sel(mtype == MAT_METAL, refl, n);
-                        f3 nd = axis;
+                        nd = axis;
                         if (m2.y >= 0.0f) {
                             // RndHemisphereVec (03 Utils.h:64-88) / RndHemisphereVec3 (04 Utils.h:132-157)
                             float u_fi = (float)(r & 0xFFFFU) * (1.0f / 65536.0f), u_th = (float)(r >> 16) * (1.0f / 65536.0f);
                             // b = Normalize(Cross(dir, dir + 0.01)) = Normalize(Cross(dir, (1,1,1))): the 0.01 and dir x dir cancel;
-                            // c = Cross(dir, b) is already unit (dir, b orthonormal), so the reference's second Normalize is a no-op
+                            // c = Cross(dir, b) needs no second Normalize here: the result is normalised below
                             f3 b = F3(axis.y - axis.z, axis.z - axis.x, axis.x - axis.y);
                             float bl2 = dot(b, b);
-                            bool degenerate = !(bl2 > 0.0f);
-                            b = b * (degenerate ? 0.0f : rsq_fast(bl2));
+                            b = b * (bl2 > 0.0f ? rsq_fast(bl2) : 0.0f);      // Normalize(0) = 0: the frame collapses for dir parallel to (1,1,1)
                             f3 c = cross(axis, b);
                             const float fi_rev = (float)((360.0 / 57.2958f) / 6.283185307179586);   // fi/(2*pi)
                             float cf = __builtin_amdgcn_cosf(u_fi * fi_rev), sf = __builtin_amdgcn_sinf(u_fi * fi_rev);
@@ -126,16 +126,17 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
                                 ct = fmaf(1.0f - m2.y, u_th, m2.y);
                                 st = sqrt_fast(fmaf(-ct, ct, 1.0f));   // ct <= 1 exactly (u_th < 1), so the fused 1 - ct*ct is never negative
                             }
-                            f3 ring = madd(c, sf, b * cf);
-                            nd = madd(ring, st, axis * ct);
-                            // Ray's constructor normalises (Common/Ray.hpp:33-34); nd is unit already unless the frame
-                            // collapsed (axis parallel to (1,1,1): Normalize(0) = 0), where it is axis*cos(theta).
-                            if (degenerate) nd = normalize(nd);
+                            nd = madd(madd(c, sf, b * cf), st, axis * ct);
                         }
+                    }
+                    // Ray's constructor normalises every scattered ray (Common/Ray.hpp:33-34).  Not optional here: the sphere
+                    // test assumes d.d = 1, and its discriminant amplifies an error in |d| (hardware sin/cos are good to
+                    // 1e-5; a normal taken at a hit point 1e-3 off a distant sphere is not unit) by (distance/radius)^2.
+                    d = normalize(nd);
+                    if (mtype != MAT_DIELECTRIC) {
                         f3 att = F3(m0);
-                        if (VARIANT == 4) att = att * fmaxf(dot(nd, n), 0.0f);     // 04 Diffuse.hpp:77-78, Metal.hpp:83-84
+                        if (VARIANT == 4) att = att * fmaxf(dot(d, n), 0.0f);      // 04 Diffuse.hpp:77-78, Metal.hpp:83-84
                         thr = thr * att;
-                        d = nd;
                     }
                     ++depth;
                 } else {
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
         }
     }
     if (inside) {
-        out[(size_t)slice * A.width * A.height + pixel] = make_float4(acc.x, acc.y, acc.z, (float)n_started);
+        // debug flag 4: report the lane's scene-query count in w instead of its sample count (parity diagnostics)
+        out[(size_t)slice * A.width * A.height + pixel] = make_float4(acc.x, acc.y, acc.z, (A.debug_flags & 4) ? (float)rays : (float)n_started);
     }
     wave_add_u64(counters + 0, rays);
 }

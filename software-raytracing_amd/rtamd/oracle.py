@@ -84,6 +84,26 @@ def render_path(scene, cam, prm, width, height, threads=1, want_sumsq=False):
     return dict(sum=s, sumsq=s2, bgra=bgra, rays=sum(totals))
 
 
+def render_path_px(scene, cam, prm, width, height, threads=1):
+    """-> dict(sum, rays, px_rays uint32 [H,W]: scene queries per pixel) - debugging aid for parity tests"""
+    L = lib()
+    L.orc_render_path_px.argtypes = [C.POINTER(abi.rt_scene), C.POINTER(abi.rt_camera), C.POINTER(abi.rt_path_params),
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    s = np.zeros((height, width, 3), np.float32)
+    px = np.zeros((height, width), np.uint32)
+    sc = scene.c()
+    totals = []
+
+    def rows(y0, y1):
+        cnt = (C.c_uint64 * 2)(0, 0)
+        rc = L.orc_render_path_px(C.byref(sc), C.byref(cam), C.byref(prm), width, height, y0, y1, _fp(s), cnt, px.ctypes.data_as(C.POINTER(C.c_uint32)))
+        assert rc == 0
+        totals.append(cnt[0])
+
+    _run_rows(rows, height, threads)
+    return dict(sum=s, rays=sum(totals), px_rays=px)
+
+
 def resolve(rgb, divisor, gamma):
     L = lib()
     rgb = np.ascontiguousarray(rgb, np.float32)
