@@ -186,6 +186,32 @@ def test_lds_and_global_scene_paths_agree(ctx):
     assert a["rays"] == b["rays"] and np.array_equal(a["rgb"], b["rgb"])
 
 
+@pytest.mark.parametrize("which", ["04", "03", "stress"])
+def test_per_pixel_ray_counts_match_oracle(ctx, which):
+    """Integer check of the whole decision chain: the number of scene queries each pixel makes (kernel diagnostics
+    flag 4 / orc_render_path_px).  Same counter RNG => same count unless a last-bit difference flips a hit or a
+    Schlick choice somewhere along one of the pixel's paths."""
+    import torch
+    if which == "04":
+        (s, cam, prm), (w, h), need = scenes.scene04(4, seed=9), (160, 120), 0.99
+    elif which == "03":
+        (s, cam, prm), (w, h), need = scenes.scene03(4, seed=9), (160, 120), 0.97
+    else:   # distant small spheres: ill-conditioned discriminants, so more last-bit flips
+        (s, cam, prm), (w, h), need = scenes.scene_stress(n_spheres=600, grid=12, spp=2, seed=9), (96, 54), 0.97
+    acc = torch.zeros(h, w, 4, device="cuda")
+    ctx.set_debug_flags(4)
+    try:
+        ctx.path_accumulate_device(s, cam, prm, w, h, acc.data_ptr())
+        st = ctx.sync()
+    finally:
+        ctx.set_debug_flags(0)
+    g = acc[:, :, 3].cpu().numpy().astype(np.int64)
+    o = oracle.render_path_px(s, cam, prm, w, h, threads=8)
+    assert g.sum() == st["rays"]
+    assert (g == o["px_rays"]).mean() >= need, (g == o["px_rays"]).mean()
+    assert abs(int(g.sum()) - int(o["rays"])) <= 5e-3 * o["rays"]
+
+
 # ---- device-buffer entry points, sharding, resolve -----------------------------------------------------
 def test_sample_range_sharding_is_additive(ctx):
     import torch
