@@ -142,7 +142,7 @@ def main():
                        "samples_per_step": W * H * SPP, "rays_per_step": rays_step, "samples_per_sec": W * H * SPP * args.steps / dt,
                        "parallelism": f"sample-range x{world}, one all-reduce(sum) of the {W * H * 16 / 1e6:.1f} MB accumulator" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": traffic, "kernel": "rt::k_path<4>", "kernel_ms": k_ms, "flops_per_ray": fpr, "rays_per_launch": rays,
+                         "traffic": traffic, "kernel": "rt::k_path<4, true>", "kernel_ms": k_ms, "flops_per_ray": fpr, "rays_per_launch": rays,
                          "note": "FP32 VALU-bound path (no MFMA, negligible HBM traffic): algorithmic FLOPs/ray x rays / kernel time vs the FP32 vector peak"},
         }
         if world == 1 and not args.no_cpu_baseline:
