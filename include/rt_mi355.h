@@ -37,7 +37,7 @@ extern "C" {
 /* ---- scene records ------------------------------------------------------------------- */
 
 /* Primitive kinds.  Sphere/Plane: 01/02 Sphere.hpp, Plane.hpp; 03 Sphere.hpp; 04 Scene/Sphere.hpp,
- * Scene/Plane.hpp.  Rectangle: 04 Scene/Rectangle.hpp.  Triangle: semantics of
+ * Scene/Plane.hpp.  Rectangle: 04 Scene/Rectangle.hpp.  Box: 04 Scene/Box.hpp.  Triangle: semantics of
  * Ray::intersectsTriangle (Common/Ray.hpp:150-212), which no reference scene element wraps. */
 enum rt_prim_type {
     RT_PRIM_SPHERE   = 0,  /* f[0..2] centre, f[3] radius                                    */
@@ -45,10 +45,14 @@ enum rt_prim_type {
                               Plane constructors normalise; this ABI takes it as given)     */
     RT_PRIM_RECT     = 2,  /* f[0..2] centre, f[3..4] width,height, f[5..7] Euler orientation
                               in degrees (04 Scene/Rectangle.hpp:31-36)                      */
-    RT_PRIM_TRIANGLE = 3   /* f[0..2] v0, f[3..5] v1, f[6..8] v2                             */
+    RT_PRIM_TRIANGLE = 3,  /* f[0..2] v0, f[3..5] v1, f[6..8] v2                             */
+    RT_PRIM_BOX      = 4   /* f[0..2] centre, f[3..5] sizes (x,y,z), f[6..8] Euler orientation in
+                              degrees; 04 Scene/Box.hpp:34-40 with its six-face test :55-158,
+                              including the y range [-sy/2, +sz/2] of the two Z faces (:88,:95);
+                              path renders only                                              */
 };
 
-#define RT_PRIM_FLAG_FLIP_NORMALS 1u /* 03 Sphere 'inverted' (Sphere.hpp:65-67), 04 'flipNormals' */
+#define RT_PRIM_FLAG_FLIP_NORMALS 1u /* 03 Sphere 'inverted' (Sphere.hpp:65-67), 04 Sphere/Box 'flipNormals' */
 
 typedef struct rt_prim {
     int32_t  type;        /* enum rt_prim_type                      */

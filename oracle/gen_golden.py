@@ -232,7 +232,46 @@ def gen_stats(L3, L4, rng):
     np.savez_compressed(os.path.join(OUT, "stat_samplers_materials.npz"), axes=axes, thetas=thetas, n=n, **res)
 
 
+def gen_boxes(L4):
+    """scene::Box (04 Scene/Box.hpp) alone and among spheres/rectangles; rays from outside and from inside the boxes."""
+    rng = np.random.default_rng(4040)
+    ns, nr, npr = 40, 200, 5
+    prims = np.zeros((ns, npr, 13), np.float32)
+    orients = [(0, 0, 0), (0, 0, 0), (90, 0, 0), (0, 45, 0), (0, 0, 30), None]
+    for s in range(ns):
+        for p in range(npr):
+            f = np.zeros(11, np.float32)
+            kind = 4 if p < 3 else int(rng.integers(0, 3))
+            flip = 0.0
+            if kind == 4:
+                f[:3] = rng.uniform(-3, 3, 3); f[3:6] = rng.uniform(0.5, 4, 3)
+                oc = orients[int(rng.integers(0, len(orients)))]
+                f[6:9] = oc if oc is not None else tuple(rng.uniform(-90, 90, 3))
+                flip = float(rng.random() < 0.3)
+            elif kind == 0:
+                f[:3] = rng.uniform(-3, 3, 3); f[3] = rng.uniform(0.3, 2.0)
+            elif kind == 1:
+                f[:3] = rng.uniform(-5, 5, 3); nn = rng.normal(size=3); f[3:6] = nn / np.linalg.norm(nn)
+            else:
+                f[:3] = rng.uniform(-3, 3, 3); f[3:5] = rng.uniform(0.5, 6, 2); f[5:8] = (rng.uniform(-180, 180), 0, 0)
+            prims[s, p, 0] = kind; prims[s, p, 1] = flip; prims[s, p, 2:] = f
+    o = rng.uniform(-4, 4, (ns, nr, 3)).astype(np.float32); d = unit(rng, ns * nr).reshape(ns, nr, 3)
+    o[:, : nr // 4] = prims[:, 0, 2:5][:, None, :] + rng.uniform(-0.2, 0.2, (ns, nr // 4, 3)).astype(np.float32)   # origins inside box 0
+    out = np.zeros((ns, nr, 8), np.float32); hit = np.zeros((ns, nr), np.int32); which = np.full((ns, nr), -1, np.int32)
+    L4.ref_e4_scene_hit.argtypes = [FP, C.c_int, FP, FP, C.c_float, C.c_float, FP, C.POINTER(C.c_int)]
+    w = C.c_int(0)
+    for s in range(ns):
+        for k in range(nr):
+            hit[s, k] = L4.ref_e4_scene_hit(fp(prims[s]), npr, fp(o[s, k]), fp(d[s, k]), 0.01, 1000.0, fp(out[s, k]), C.byref(w))
+            which[s, k] = w.value if hit[s, k] else -1
+    np.savez_compressed(os.path.join(OUT, "kat_box_e4.npz"), prims=prims, o=o, d=d, hit=hit, out=out * hit[..., None], which=which)
+    print("box scenes: hit rate", hit.mean(), "box hits", np.isin(which, [0, 1, 2]).mean())
+
+
 if __name__ == "__main__":
+    import sys
+    if sys.argv[1:] == ["boxes"]:          # added later: leaves the other fixtures (one shared generator state) untouched
+        gen_boxes(load(4)); raise SystemExit
     rng = np.random.default_rng(20201)
     L1, L3, L4 = load(1), load(3), load(4)
     gen_math(L1, rng)

@@ -9,6 +9,7 @@
 #include "Scene/Sphere.hpp"
 #include "Scene/Plane.hpp"
 #include "Scene/Rectangle.hpp"
+#include "Scene/Box.hpp"
 #include "Materials/Diffuse.hpp"
 #include "Materials/Metal.hpp"
 #include "Materials/Refractive.hpp"
@@ -29,7 +30,7 @@ struct Tag : materials::Material {
 };
 
 extern "C" {
-// prims: n records of 13 floats {type(0 sphere,1 plane,2 rect), flip, f[0..10]} in rt_prim field order; closest hit via scene::List.
+// prims: n records of 13 floats {type(0 sphere,1 plane,2 rect,4 box), flip, f[0..10]} in rt_prim field order; closest hit via scene::List.
 int ref_e4_scene_hit(const float* prims, int n, const float* o, const float* d, float tmin, float tmax, float* out8, int* which) {
     scene::List list;
     for (int i = 0; i < n; ++i) {
@@ -37,6 +38,7 @@ int ref_e4_scene_hit(const float* prims, int n, const float* o, const float* d, 
         auto tag = std::make_shared<Tag>(i);
         if (p[0] == 0.0f) list.addElement(std::make_shared<scene::Sphere>(tag, v(f), f[3], p[1] != 0.0f));
         else if (p[0] == 1.0f) list.addElement(std::make_shared<scene::Plane>(tag, v(f), v(f + 3)));
+        else if (p[0] == 4.0f) list.addElement(std::make_shared<scene::Box>(tag, v(f), v(f + 3), v(f + 6), p[1] != 0.0f));
         else list.addElement(std::make_shared<scene::Rectangle>(tag, v(f), math::Vec2<float>(f[3], f[4]), v(f + 5)));
     }
     HitInfo h{};

@@ -148,6 +148,25 @@ static int ray_rect_xy(const ray_t* r, float z, float xmin, float xmax, float ym
     }
     return 0;
 }
+/* Ray::intersectsAARectangleYz (:297-317) and ...Xz (:331-351). */
+static int ray_rect_yz(const ray_t* r, float x, float ymin, float ymax, float zmin, float zmax, float tmin, float tmax, float* tout) {
+    float t = (x - r->o.x) / r->d.x;
+    if (t > 0 && t >= tmin && t <= tmax) {
+        float y = r->o.y + r->d.y * t;
+        float z = r->o.z + r->d.z * t;
+        if (y >= ymin && y <= ymax && z >= zmin && z <= zmax) { if (tout) *tout = t; return 1; }
+    }
+    return 0;
+}
+static int ray_rect_xz(const ray_t* r, float y, float xmin, float xmax, float zmin, float zmax, float tmin, float tmax, float* tout) {
+    float t = (y - r->o.y) / r->d.y;
+    if (t > 0 && t >= tmin && t <= tmax) {
+        float x = r->o.x + r->d.x * t;
+        float z = r->o.z + r->d.z * t;
+        if (x >= xmin && x <= xmax && z >= zmin && z <= zmax) { if (tout) *tout = t; return 1; }
+    }
+    return 0;
+}
 /* Ray::intersectsTriangle (:150-212): plane hit, then barycentrics through Inverse([e2 e1 n]). */
 static int ray_triangle(const ray_t* r, v3 v0, v3 v1, v3 v2, float tmin, float tmax, float* tout, float* bary) {
     v3 e1 = sub(v1, v0), e2 = sub(v2, v0);
@@ -280,6 +299,35 @@ static int prim_hit_path(const rt_prim* p, const ray_t* r, float tmin, float tma
             return 1;
         }
         return 0;
+    }
+    case RT_PRIM_BOX: {   /* scene::Box::intersectsRay (04 Scene/Box.hpp:55-158), face by face, quirks kept */
+        v3 orient = pv(p->f + 6);
+        m3 inv = rotation_mat(neg(orient));                                   /* :62 */
+        v3 pos = pv(p->f);
+        ray_t tr = make_ray(m3_mulv(&inv, sub(r->o, pos)), m3_mulv(&inv, r->d)); /* :65-67 */
+        float hw = p->f[3] / 2.0f, hh = p->f[4] / 2.0f, hl = p->f[5] / 2.0f;   /* :70-72 */
+        float tclosest = tmax;
+        int any = 0;
+        v3 nc = V(0, 0, 0);
+        /* the two Z faces take y in [-halfHeight, +halfLength] (:88, :95), as written in the reference */
+        if (ray_rect_xy(&tr, -hl, -hw, hw, -hh, hl, tmin, tclosest, &t)) { any = 1; tclosest = t; nc = V(0.0f, 0.0f, -1.0f); }
+        if (ray_rect_xy(&tr, hl, -hw, hw, -hh, hl, tmin, tclosest, &t)) { any = 1; tclosest = t; nc = V(0.0f, 0.0f, 1.0f); }
+        if (ray_rect_yz(&tr, -hw, -hh, hh, -hl, hl, tmin, tclosest, &t)) { any = 1; tclosest = t; nc = V(-1.0f, 0.0f, 0.0f); }
+        if (ray_rect_yz(&tr, hw, -hh, hh, -hl, hl, tmin, tclosest, &t)) { any = 1; tclosest = t; nc = V(1.0f, 0.0f, 0.0f); }
+        if (ray_rect_xz(&tr, -hh, -hw, hw, -hl, hl, tmin, tclosest, &t)) { any = 1; tclosest = t; nc = V(0.0f, -1.0f, 0.0f); }
+        if (ray_rect_xz(&tr, hh, -hw, hw, -hl, hl, tmin, tclosest, &t)) { any = 1; tclosest = t; nc = V(0.0f, 1.0f, 0.0f); }
+        if (any) {
+            h->t = t;                                                           /* :136: the last accepted face is the closest */
+            h->point = add(r->o, muls(r->d, t));
+            h->normal = nc;
+            h->front = 1;
+            h->material = p->material;
+            if (p->flags & RT_PRIM_FLAG_FLIP_NORMALS) h->normal = neg(h->normal);
+            if (dot3(neg(tr.d), h->normal) < 0.0f) { h->normal = neg(h->normal); h->front = 0; }
+            m3 rot = rotation_mat(orient);
+            h->normal = m3_mulv(&rot, h->normal);                               /* :154 */
+        }
+        return any;
     }
     case RT_PRIM_TRIANGLE: /* extension: Plane wrapper semantics over Ray::intersectsTriangle */
         if (ray_triangle(r, pv(p->f), pv(p->f + 3), pv(p->f + 6), tmin, tmax, &t, NULL)) {

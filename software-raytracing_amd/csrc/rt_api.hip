@@ -124,8 +124,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
             switch (P.type) {
             case RT_PRIM_SPHERE: {
                 G = f4(f[0], f[1], f[2], f[3] * f[3]);
-                float k = 1.0f / f[3];
-                A = f4(f[0], f[1], f[2], (P.flags & RT_PRIM_FLAG_FLIP_NORMALS) ? -k : k);
+                A = f4(f[0], f[1], f[2], (P.flags & RT_PRIM_FLAG_FLIP_NORMALS) ? -1.0f : 1.0f);
                 break; }
             case RT_PRIM_PLANE: {
                 int axis = -1;    // unit normal exactly +-e_axis: shares 1/d per ray (bit-identical to the general form)
@@ -162,6 +161,39 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
                 B = f4(n[0], n[1], n[2], 0); C = B;
                 wide = true;
                 break; }
+            case RT_PRIM_BOX: {
+                // scene::Box (04 Scene/Box.hpp:55-158) tests its six faces in a fixed order against a shrinking tMax - exactly
+                // what the element list does with consecutive elements - so a box is flattened into six rectangle slots in
+                // that order.  Object frame rows x,y,z = GetRotationMat(-orientation); face normals leave through
+                // GetRotationMat(+orientation) (:154), the side is decided in the object frame (:148).
+                float neg[3] = {-f[6], -f[7], -f[8]}, pos[3] = {f[6], f[7], f[8]}, ri[9], rf[9];
+                rotation_mat(neg, ri); rotation_mat(pos, rf);
+                const float hw = f[3] / 2.0f, hh = f[4] / 2.0f, hl = f[5] / 2.0f;
+                auto dotc = [&](int row) { return ri[3 * row] * f[0] + ri[3 * row + 1] * f[1] + ri[3 * row + 2] * f[2]; };
+                const float flip = (P.flags & RT_PRIM_FLAG_FLIP_NORMALS) ? -1.0f : 1.0f;
+                // face: plane axis, its offset, the two in-plane axes with their [lo, hi] ranges, local normal sign
+                struct Face { int ax; float off; int u; float ulo, uhi; int v; float vlo, vhi; float sgn; };
+                const Face faces[6] = {
+                    {2, -hl, 0, -hw, hw, 1, -hh, hl, -1.0f}, {2, hl, 0, -hw, hw, 1, -hh, hl, 1.0f},      // y up to +halfLength: as written (:88, :95)
+                    {0, -hw, 1, -hh, hh, 2, -hl, hl, -1.0f}, {0, hw, 1, -hh, hh, 2, -hl, hl, 1.0f},
+                    {1, -hh, 0, -hw, hw, 2, -hl, hl, -1.0f}, {1, hh, 0, -hw, hw, 2, -hl, hl, 1.0f}};
+                for (const Face& F : faces) {
+                    const float s = F.sgn * flip;
+                    const float umid = 0.5f * (F.ulo + F.uhi), vmid = 0.5f * (F.vlo + F.vhi);   // asymmetric ranges: |u - mid| <= half
+                    H.slots.push_back(f4(ri[3 * F.ax], ri[3 * F.ax + 1], ri[3 * F.ax + 2], dotc(F.ax) + F.off));          // G
+                    H.slots.push_back(f4(0, 0, 0, 0));                                                                   // A
+                    H.slot_mat_fixups.push_back(H.slots.size());
+                    H.slots.push_back(f4(s * rf[F.ax], s * rf[3 + F.ax], s * rf[6 + F.ax], __builtin_bit_cast(float, mat)));  // B: R(+o) column
+                    H.slots.push_back(f4(s * ri[3 * F.ax], s * ri[3 * F.ax + 1], s * ri[3 * F.ax + 2], 0));              // C: R(-o) row
+                    H.slots.push_back(f4(ri[3 * F.u], ri[3 * F.u + 1], ri[3 * F.u + 2], -dotc(F.u) - umid));             // G1
+                    H.slots.push_back(f4(ri[3 * F.v], ri[3 * F.v + 1], ri[3 * F.v + 2], -dotc(F.v) - vmid));             // G2
+                    H.slots.push_back(f4(0.5f * (F.uhi - F.ulo), 0.5f * (F.vhi - F.vlo), 0, 0));                         // G3
+                    H.slots.push_back(f4(0, 0, 0, 0));
+                    if (!H.runs.empty() && H.runs.back().x == PRIM_RECT) H.runs.back().z++;
+                    else H.runs.push_back(make_int4(PRIM_RECT, 0, 1, i));
+                }
+                H.info.push_back(make_int4(PRIM_RECT, 0, mat, (int)P.flags));
+                continue; }
             default: return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": unknown type " + std::to_string(P.type));
             }
             B.w = __builtin_bit_cast(float, mat);
@@ -177,7 +209,8 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         // Whitted scenes (01/02): the IEEE-exact layout of rt_strict.h
         case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], f[3])); break;
         case RT_PRIM_PLANE: H.geom.push_back(f4(f[3], f[4], f[5], 0)); H.geom.push_back(f4(f[0], f[1], f[2], 0)); break;   // n, p0
-        case RT_PRIM_RECT: return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles exist only in the path-tracing examples");
+        case RT_PRIM_RECT: case RT_PRIM_BOX:
+            return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles and boxes exist only in the path-tracing examples");
         case RT_PRIM_TRIANGLE: {
             float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
             float n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};   // cross(e2,e1), Ray.hpp:159

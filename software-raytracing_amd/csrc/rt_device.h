@@ -115,8 +115,8 @@ __device__ __forceinline__ void rng_pair(uint32_t skey, uint32_t ctr, float& a, 
 // G..G3 feed the ray test, A,B,C feed shading and sit at the same offsets for every type, so the closest-hit
 // loop only has to remember WHERE the winner is (its byte offset in the blob), not what it is:
 //   A = (c.xyz, k)   B = (m.xyz, byte offset of the material record)   C = (f.xyz, 0)
-//   normal n = (p - c)*k + m, facing vector (p - c)*k + f; the hit is a back face when dot(d, facing) > 0.
-//     sphere: c = centre, k = +-1/r ('inverted' negates), m = f = 0      (03 Sphere.hpp:57-73, 04 Scene/Sphere.hpp:58-74)
+//   normal n = (p - c)*k/|p - c| + m, facing vector (p - c)*k/|p - c| + f; the hit is a back face when dot(d, facing) > 0.
+//     sphere: c = centre, k = +-1 ('inverted' negates), m = f = 0: Normalize(p - c)   (03 Sphere.hpp:57-73, 04 Scene/Sphere.hpp:58-74)
 //     planes, triangle: c = 0, k = 0, m = f = unit normal               (04 Scene/Plane.hpp:55-66)
 //     rectangle: m = GetRotationMat(orientation)*(0,0,1), f = row 2 of GetRotationMat(-orientation): the reference
 //                decides the side in object space and rotates the normal out with the OTHER matrix (Rectangle.hpp:58-92)

@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
                 float4 sa = M.ld4(hit + SLOT_A), sb = M.ld4(hit + SLOT_B), sc = M.ld4(hit + SLOT_C);
                 o = madd(d, t, o);                       // the hit point is the next origin; nothing below needs the old one
                 f3 pc = o - F3(sa);
-                f3 n = madd(pc, sa.w, F3(sb));
-                float facing = dot(d, madd(pc, sa.w, F3(sc)));
+                // spheres: Normalize(p - c) (k = +-1; also right when the hit was reported at tMax, off the surface); others: k = 0
+                float k = sa.w * rsq_fast(fmaf(pc.z, pc.z, fmaf(pc.y, pc.y, fmaf(pc.x, pc.x, 1e-30f))));
+                f3 n = madd(pc, k, F3(sb));
+                float facing = dot(d, madd(pc, k, F3(sc)));
                 bool back = facing > 0.0f;
                 // n = back ? -n : n through the sign bit of (0 - facing): set exactly when facing > 0
                 uint32_t flip = __float_as_uint(0.0f - facing) & 0x80000000U;
@@ -111,28 +113,37 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
                             // RndHemisphereVec (03 Utils.h:64-88) / RndHemisphereVec3 (04 Utils.h:132-157)
                             float u_fi = (float)(r & 0xFFFFU) * (1.0f / 65536.0f), u_th = (float)(r >> 16) * (1.0f / 65536.0f);
                             // b = Normalize(Cross(dir, dir + 0.01)) = Normalize(Cross(dir, (1,1,1))): the 0.01 and dir x dir cancel;
-                            // c = Cross(dir, b) needs no second Normalize here: the result is normalised below
+                            // c = Cross(dir, b) is already unit (dir, b orthonormal), so the reference's second Normalize is a no-op
                             f3 b = F3(axis.y - axis.z, axis.z - axis.x, axis.x - axis.y);
                             float bl2 = dot(b, b);
-                            b = b * (bl2 > 0.0f ? rsq_fast(bl2) : 0.0f);      // Normalize(0) = 0: the frame collapses for dir parallel to (1,1,1)
+                            bool degenerate = !(bl2 > 0.0f);
+                            b = b * (degenerate ? 0.0f : rsq_fast(bl2));      // Normalize(0) = 0: the frame collapses for dir parallel to (1,1,1)
                             f3 c = cross(axis, b);
+                            // fi = U*360/57.2958; cos from the hardware (input in revolutions), sin = +-sqrt(1 - cos^2) so that
+                            // cos^2 + sin^2 = 1 to the last bit: v_sin/v_cos are each good to ~1e-5 only, and the sphere test
+                            // amplifies an error in |d| by (distance/radius)^2
                             const float fi_rev = (float)((360.0 / 57.2958f) / 6.283185307179586);   // fi/(2*pi)
-                            float cf = __builtin_amdgcn_cosf(u_fi * fi_rev), sf = __builtin_amdgcn_sinf(u_fi * fi_rev);
+                            float x_rev = u_fi * fi_rev;
+                            float cf = __builtin_amdgcn_cosf(x_rev);
+                            float sf = sqrt_fast(fmaf(-cf, cf, 1.0f));
+                            sf = __uint_as_float(__float_as_uint(sf) | (__float_as_uint(0.5f - x_rev) & 0x80000000U));   // negative beyond half a turn
                             float ct, st;
                             if (VARIANT == 3) {   // theta = U(-1,1)*thetaMax/57.2958
                                 float th_rev = (2.0f * u_th - 1.0f) * m2.y * 0.15915494309189535f;
-                                ct = __builtin_amdgcn_cosf(th_rev); st = __builtin_amdgcn_sinf(th_rev);
+                                ct = __builtin_amdgcn_cosf(th_rev);
+                                st = sqrt_fast(fmaf(-ct, ct, 1.0f));
+                                st = __uint_as_float(__float_as_uint(st) | (__float_as_uint(th_rev) & 0x80000000U));      // |theta| <= 90 deg: sin has theta's sign
                             } else {              // theta = acos(U(cos(thetaMax/57.2958), 1))
                                 ct = fmaf(1.0f - m2.y, u_th, m2.y);
                                 st = sqrt_fast(fmaf(-ct, ct, 1.0f));   // ct <= 1 exactly (u_th < 1), so the fused 1 - ct*ct is never negative
                             }
                             nd = madd(madd(c, sf, b * cf), st, axis * ct);
+                            // Ray's constructor normalises (Common/Ray.hpp:33-34); nd is unit by construction unless the frame
+                            // collapsed, where it is axis*cos(theta)
+                            if (degenerate) nd = normalize(nd);
                         }
                     }
-                    // Ray's constructor normalises every scattered ray (Common/Ray.hpp:33-34).  Not optional here: the sphere
-                    // test assumes d.d = 1, and its discriminant amplifies an error in |d| (hardware sin/cos are good to
-                    // 1e-5; a normal taken at a hit point 1e-3 off a distant sphere is not unit) by (distance/radius)^2.
-                    d = normalize(nd);
+                    d = nd;   // unit: n is unit (slot layout), Reflect/Refract keep the length, the sampled direction is unit by construction
                     if (mtype != MAT_DIELECTRIC) {
                         f3 att = F3(m0);
                         if (VARIANT == 4) att = att * fmaxf(dot(d, n), 0.0f);      // 04 Diffuse.hpp:77-78, Metal.hpp:83-84

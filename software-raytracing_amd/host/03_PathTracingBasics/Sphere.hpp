@@ -1,5 +1,5 @@
 // Sphere (03): (position, radius, material, inverted) as Sources/03_PathTracingBasics/Sphere.hpp:29-75: the normal
-// is (p - c)/r, negated when 'inverted', then turned against the ray with frontFaceSurface recording which side.
+// is Normalize(p - c), negated when 'inverted', then turned against the ray with frontFaceSurface recording which side.
 #pragma once
 #include "Utils.h"
 
@@ -17,7 +17,7 @@ public:
         if (hitInfo) {
             hitInfo->t = t;
             hitInfo->point = ray.getOrigin() + (ray.getDirection() * t);
-            hitInfo->normal = (hitInfo->point - position_) / radius_;
+            hitInfo->normal = math::Normalize(hitInfo->point - position_);
             if (inverted_) hitInfo->normal = -hitInfo->normal;
             hitInfo->frontFaceSurface = true;
             hitInfo->materialPtr = materialPtr_;

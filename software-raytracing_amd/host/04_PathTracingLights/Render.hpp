@@ -5,6 +5,7 @@
 #include "Materials/Light.hpp"
 #include "Materials/Metal.hpp"
 #include "Materials/Refractive.hpp"
+#include "Scene/Box.hpp"
 #include "Scene/Plane.hpp"
 #include "Scene/Rectangle.hpp"
 #include "Scene/Sphere.hpp"

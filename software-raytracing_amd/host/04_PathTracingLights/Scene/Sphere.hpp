@@ -17,7 +17,7 @@ public:
         if (hitInfo) {
             hitInfo->t = t;
             hitInfo->point = ray.getOrigin() + (ray.getDirection() * t);
-            hitInfo->normal = (hitInfo->point - position_) / radius_;
+            hitInfo->normal = math::Normalize(hitInfo->point - position_);
             if (inverted_) hitInfo->normal = -hitInfo->normal;
             hitInfo->materialPtr = materialPtr_;
             detail::face_forward(ray.getDirection(), hitInfo);

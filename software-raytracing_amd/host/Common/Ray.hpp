@@ -49,6 +49,22 @@ public:
         if (tOut) *tOut = t;
         return true;
     }
+    bool intersectsAARectangleYz(float x, float yMin, float yMax, float zMin, float zMax, float tMin, float tMax, float* tOut) const {
+        const float t = (x - origin_.x) / direction_.x;
+        if (!(t > 0 && t >= tMin && t <= tMax)) return false;
+        const float y = origin_.y + direction_.y * t, z = origin_.z + direction_.z * t;
+        if (!(y >= yMin && y <= yMax && z >= zMin && z <= zMax)) return false;
+        if (tOut) *tOut = t;
+        return true;
+    }
+    bool intersectsAARectangleXz(float y, float xMin, float xMax, float zMin, float zMax, float tMin, float tMax, float* tOut) const {
+        const float t = (y - origin_.y) / direction_.y;
+        if (!(t > 0 && t >= tMin && t <= tMax)) return false;
+        const float x = origin_.x + direction_.x * t, z = origin_.z + direction_.z * t;
+        if (!(x >= xMin && x <= xMax && z >= zMin && z <= zMax)) return false;
+        if (tOut) *tOut = t;
+        return true;
+    }
     // clockwise winding: normal = normalize(cross(v2-v0, v1-v0)); barycentric x goes with (v2-v0), y with (v1-v0)
     bool intersectsTriangle(const Vec3<float>& v0, const Vec3<float>& v1, const Vec3<float>& v2, float tMin, float tMax, float* tOut, Vec2<float>* bary) const {
         const Vec3<float> e1 = v1 - v0, e2 = v2 - v0, n = Normalize(Cross(e2, e1));

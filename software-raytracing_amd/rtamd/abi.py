@@ -8,7 +8,7 @@ RT_ERR_HIP = -3
 RT_ERR_NO_DEVICE = -4
 RT_ERR_TOO_LARGE = -5
 
-RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_RECT, RT_PRIM_TRIANGLE = 0, 1, 2, 3
+RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_RECT, RT_PRIM_TRIANGLE, RT_PRIM_BOX = 0, 1, 2, 3, 4
 RT_PRIM_FLAG_FLIP_NORMALS = 1
 RT_MAT_PHONG, RT_MAT_DIFFUSE, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_LIGHT = 0, 1, 2, 3, 4
 RT_PATH_SKY, RT_PATH_LIGHTS = 3, 4

@@ -68,6 +68,10 @@ class Scene:
     def rect(self, material, position, sizes=(1, 1), orientation=(0, 0, 0)):
         return self._add_prim(abi.RT_PRIM_RECT, material, [*position, *sizes, *orientation])
 
+    def box(self, material, position, sizes=(1, 1, 1), orientation=(0, 0, 0), flip=False):
+        """04 Scene/Box.hpp:34-40"""
+        return self._add_prim(abi.RT_PRIM_BOX, material, [*position, *sizes, *orientation], abi.RT_PRIM_FLAG_FLIP_NORMALS if flip else 0)
+
     def triangle(self, material, v0, v1, v2):
         return self._add_prim(abi.RT_PRIM_TRIANGLE, material, [*v0, *v1, *v2])
 
@@ -215,7 +219,7 @@ def scene_stress(n_spheres=10000, grid=64, spp=4096, seed=1):
 
 # algorithmic FLOPs per ray: 17/sphere, 12/plane, 38/rect, 45/triangle + shade
 def flops_per_ray(scene, shade):
-    n = {0: 0, 1: 0, 2: 0, 3: 0}
+    n = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}
     for p in scene.prims:
         n[p.type] += 1
-    return 17 * n[0] + 12 * n[1] + 38 * n[2] + 45 * n[3] + shade
+    return 17 * n[0] + 12 * n[1] + 38 * (n[2] + 6 * n[4]) + 45 * n[3] + shade     # a box is six rectangle tests

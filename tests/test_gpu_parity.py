@@ -161,6 +161,27 @@ def test_mixed_primitives_path(ctx):
     assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=1e-2)
 
 
+def test_boxes_path(ctx):
+    """scene::Box (04 Scene/Box.hpp): axis-aligned, rotated about one and three axes, flipped (a room seen from inside),
+    with a light inside the room; the library flattens each box into six rectangle slots."""
+    s = scenes.Scene()
+    white = s.diffuse((0.75, 0.75, 0.75)); red = s.diffuse((0.7, 0.1, 0.1)); metal = s.metal((0.8, 0.8, 0.9), 0.15); glass = s.dielectric(0.65)
+    lm = s.light_material((12, 12, 12))
+    s.box(white, (0, 0, -6), (14, 10, 16), (0, 0, 0), flip=True)          # the room
+    s.box(red, (-2.5, -3.5, -7), (2.5, 3, 2.5), (0, 30, 0)); s.box(metal, (2.5, -3, -8), (2, 4, 2), (10, -25, 5))
+    s.box(glass, (0, -4, -4.5), (1.5, 2, 1.5), (0, 45, 0)); s.sphere(white, (-4, -4, -4), 1.0)
+    s.rect(lm, (0, 4.9, -6), (4, 4), (90, 0, 0))
+    cam = scenes.camera(70.0, (0, 0, 1.5), (-5, 0, 0))
+    prm = scenes.path_params(abi.RT_PATH_LIGHTS, 16, max_depth=6, seed=11)
+    g = ctx.render_path(s, cam, prm, 160, 120)
+    o = oracle.render_path(s, cam, prm, 160, 120, threads=8)
+    om = o["sum"] / 16
+    assert om.mean() > 0.05                                            # the scene is lit: the comparison is not black against black
+    assert abs(g["rays"] - o["rays"]) <= 5e-3 * o["rays"]
+    assert frac_within(g["rgb"], om, 1e-3) >= 0.97
+    assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=1e-2)
+
+
 def test_stress_scene_reduced_global_memory_path(ctx):
     """SURVEY.md 8(d) config 5 at reduced counts (600 spheres, 12x12x2 triangles): the flattened scene no longer
     fits the 48 KB LDS staging limit, so the kernel reads it from global memory (scalar loads) - same results."""

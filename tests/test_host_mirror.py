@@ -80,6 +80,24 @@ def test_host_ray_tests_match_reference_vectors(H):
             assert np.float32(t.value) == c["tr_t"][i] and np.float32(b[0]) == c["tr_b"][i][0] and np.float32(b[1]) == c["tr_b"][i][1], ("tri", i)
 
 
+@pytest.mark.parametrize("fixture,tmin", [("kat_scene_e4.npz", 0.01), ("kat_box_e4.npz", 0.01)])
+def test_host_04_scene_classes_match_reference_vectors(fixture, tmin):
+    """scene::List over Sphere / Plane / Rectangle / Box of the host mirror: same closest element, t, point, normal and
+    side as the reference's own classes, bit for bit (incl. exact ties: the last element wins)."""
+    L = C.CDLL(_need(os.path.join(BIN, "libhostmirror_e4.so")))
+    L.hm_e4_scene_hit.argtypes = [FP, C.c_int, FP, FP, C.c_float, C.c_float, FP, C.POINTER(C.c_int)]
+    k = np.load(os.path.join(GOLDEN, fixture))
+    out = np.zeros(8, np.float32); which = C.c_int(0)
+    for s in range(0, k["prims"].shape[0], 2):      # every second scene: 4000 rays per fixture
+        prims = np.ascontiguousarray(k["prims"][s])
+        for r in range(k["o"].shape[1]):
+            o, d = np.ascontiguousarray(k["o"][s, r]), np.ascontiguousarray(k["d"][s, r])
+            h = L.hm_e4_scene_hit(fp(prims), prims.shape[0], fp(o), fp(d), tmin, 1000.0, fp(out), C.byref(which))
+            assert h == k["hit"][s, r], (s, r)
+            if h:
+                assert which.value == k["which"][s, r] and same(out, k["out"][s, r]), (s, r, out, k["out"][s, r])
+
+
 def _load_dump(path):
     raw = open(path, "rb").read()
     n = np.frombuffer(raw, np.int32, 3)
