@@ -72,7 +72,19 @@ struct HostScene {
     std::vector<float4> geom, mats, lights;
     std::vector<float4> slots;            // path scenes (variant 3/4): the slot section of rt_device.h
     std::vector<size_t> slot_mat_fixups;  // indices into slots of the B records; B.w holds the material index until upload
+    std::vector<int4> chunks;             // path scenes: {first slot byte offset (in the slot section), bytes, first run, n runs}
     int has_aa = 0;
+    // Appends one slot of n float4 already pushed to 'slots' to the run/chunk tables: runs never straddle a chunk, so a
+    // scene too large for LDS can be walked chunk by chunk (k_path_tiled).
+    void add_slot(int dtype, size_t n_f4, int prim) {
+        const int bytes = (int)(n_f4 * 16);
+        const int start = (int)(slots.size() * 16) - bytes;
+        bool new_chunk = chunks.empty() || chunks.back().y + bytes > RT_TILE_BYTES;
+        if (new_chunk) chunks.push_back(make_int4(start, 0, (int)runs.size(), 0));
+        if (!new_chunk && !runs.empty() && runs.back().x == dtype) runs.back().z++;
+        else { runs.push_back(make_int4(dtype, 0, 1, prim)); chunks.back().w++; }
+        chunks.back().y += bytes;
+    }
 };
 
 float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
@@ -189,8 +201,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
                     H.slots.push_back(f4(ri[3 * F.v], ri[3 * F.v + 1], ri[3 * F.v + 2], -dotc(F.v) - vmid));             // G2
                     H.slots.push_back(f4(0.5f * (F.uhi - F.ulo), 0.5f * (F.vhi - F.vlo), 0, 0));                         // G3
                     H.slots.push_back(f4(0, 0, 0, 0));
-                    if (!H.runs.empty() && H.runs.back().x == PRIM_RECT) H.runs.back().z++;
-                    else H.runs.push_back(make_int4(PRIM_RECT, 0, 1, i));
+                    H.add_slot(PRIM_RECT, 8, i);
                 }
                 H.info.push_back(make_int4(PRIM_RECT, 0, mat, (int)P.flags));
                 continue; }
@@ -200,8 +211,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
             H.slots.push_back(G); H.slots.push_back(A); H.slot_mat_fixups.push_back(H.slots.size()); H.slots.push_back(B); H.slots.push_back(C);
             if (wide) { H.slots.push_back(G1); H.slots.push_back(G2); H.slots.push_back(G3); H.slots.push_back(f4(0, 0, 0, 0)); }
             // rectangles and triangles share one loop in the kernel but not one run: the run type picks the inside test
-            if (!H.runs.empty() && H.runs.back().x == dtype) H.runs.back().z++;
-            else H.runs.push_back(make_int4(dtype, 0, 1, i));
+            H.add_slot(dtype, wide ? 8 : 4, i);
             H.info.push_back(make_int4(dtype, 0, mat, (int)P.flags));
             continue;
         }
@@ -243,7 +253,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
 int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
     // one spare zero record after the runs: the path kernels prefetch runs[r + 1]
-    size_t o_runs = 0, o_geom = pad(o_runs + (H.runs.size() + 1) * 16), o_info = pad(o_geom + H.geom.size() * 16),
+    size_t o_runs = 0, o_chunks = pad(o_runs + (H.runs.size() + 1) * 16), o_geom = pad(o_chunks + H.chunks.size() * 16), o_info = pad(o_geom + H.geom.size() * 16),
            o_slots = pad(o_info + (H.slots.empty() ? H.info.size() : 0) * 16), o_mats = pad(o_slots + H.slots.size() * 16),
            o_lights = pad(o_mats + H.mats.size() * 16), total = pad(o_lights + H.lights.size() * 16 + 16);
     if (total > c->h_stage_cap) {
@@ -257,7 +267,12 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     HIPCHK(c, hipStreamSynchronize(st));
     char* h = (char*)c->h_stage;
     memset(h, 0, o_geom);
-    memcpy(h + o_runs, H.runs.data(), H.runs.size() * 16); memcpy(h + o_geom, H.geom.data(), H.geom.size() * 16);
+    memcpy(h + o_runs, H.runs.data(), H.runs.size() * 16);
+    for (size_t k = 0; k < H.chunks.size(); ++k) {   // slot-section offsets -> blob byte offsets
+        int4 ch = H.chunks[k]; ch.x += (int)o_slots;
+        memcpy(h + o_chunks + k * 16, &ch, 16);
+    }
+    memcpy(h + o_geom, H.geom.data(), H.geom.size() * 16);
     if (H.slots.empty()) memcpy(h + o_info, H.info.data(), H.info.size() * 16);
     memcpy(h + o_slots, H.slots.data(), H.slots.size() * 16);
     for (size_t b : H.slot_mat_fixups) {   // material index -> byte offset of its record in the blob
@@ -273,6 +288,7 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     D.off_mats = (int)(o_mats / 16); D.off_lights = (int)(o_lights / 16); D.total_f4 = (int)(total / 16);
     D.n_runs = (int)H.runs.size(); D.n_prims = (int)H.info.size(); D.n_mats = (int)H.mats.size() / 3; D.n_lights = (int)H.lights.size() / 2;
     D.has_aa = H.has_aa; D.off_slots = (int)(o_slots / 16);
+    D.off_chunks = (int)(o_chunks / 16); D.n_chunks = (int)H.chunks.size();
     return RT_OK;
 }
 
@@ -400,7 +416,9 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     A.width = width; A.height = height; A.sample_begin = s0; A.sample_end = s1; A.max_depth = p->max_depth;
     A.jitter = p->spp > 1; A.seed = p->seed; A.t_min = p->t_min; A.t_min_pos = p->t_min > 0.0f ? p->t_min : 1.401298464e-45f; A.t_max = p->t_max;
     A.debug_flags = c->debug_flags;
-    A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : (p->variant == RT_PATH_LIGHTS ? 16 : 8);
+    // camera code costs about as much as testing 20 primitives: with few primitives wait for a batch of idle lanes,
+    // with many refill every idle lane at once (measured: tools/sweep_regen.py, tools/sweep_regen_stress.py)
+    A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : (scene->n_prims >= 128 ? 1 : (p->variant == RT_PATH_LIGHTS ? 16 : 8));
     float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 03 Main.cpp:317
     float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
     A.inv_w2 = 2.0f / w; A.inv_h2 = 2.0f / h; A.kx = th * w / h; A.ky = th;

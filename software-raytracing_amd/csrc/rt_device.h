@@ -30,6 +30,7 @@ struct DevScene {
     int n_runs, n_prims, n_mats, n_lights;
     int has_aa;     // any axis-aligned plane run
     int off_slots;  // path scenes: float4 offset of the slot section (see "slot layout" below); geom/info unused there
+    int off_chunks, n_chunks;   // path scenes: int4 {blob byte offset, bytes, first run, n runs} per <= RT_TILE_BYTES piece of the slots
 };
 
 // Section pointers over either the global blob (wave-uniform reads become scalar loads) or its LDS copy
@@ -126,6 +127,7 @@ __device__ __forceinline__ void rng_pair(uint32_t skey, uint32_t ctr, float& a, 
 // runs (int4 {device type, -, count, -} per maximal run of one type) are read with scalar loads from the GLOBAL blob
 // even when the slots are staged in LDS: they steer uniform control flow, which wants SGPRs, while primitive
 // operands want VGPRs (an SGPR operand halves VALU issue rate on gfx950, profiles/r01_valu_issue_rates_ubench.txt).
+#define RT_TILE_BYTES 16384   /* k_path_tiled stages the slot section through LDS in pieces of at most this size */
 enum { SLOT_BYTES = 64, SLOT_A = 16, SLOT_B = 32, SLOT_C = 48, SLOT_G1 = 64, SLOT_G2 = 80, SLOT_G3 = 96 };
 
 // Scene memory: either the global blob (base pointer + byte offset; uniform offsets become scalar loads) or its LDS
@@ -151,18 +153,15 @@ template <bool LDS> struct SceneMem {
 
 // Closest hit, 03 Scene::intersectsRay / 04 scene::List::intersectsRay (03 Utils.h:255-271, 04 Utils.h:362-390):
 // tMax shrinks to the closest hit so far and a test accepts t <= tMax, so the LAST element wins exact ties.
-// q = SceneMem address of the first slot.  Returns the address of the winning slot (0 = miss: address 0 is the runs
-// section, or the first bytes of LDS, never a slot).
+// closest_hit_runs walks n_runs runs whose first slot is at SceneMem address q and updates (closest, best) in place, so a
+// scene can be walked in pieces (k_path_tiled).
 // All traced directions are unit vectors (Ray's constructor normalises), so a = d.d = 1 in the sphere test.
 template <bool LDS>
-__device__ __forceinline__ uint32_t closest_hit_slots(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
-                                                      f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {
-    uint32_t best = 0U;
-    float closest = tmax;
+__device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
+                                                 f3 o, f3 d, f3 inv_d, float tmin, float tminp, float& closest, uint32_t& best) {
     // LDS addresses are VGPR operands of ds_read anyway: keep the cursor in a VGPR (one v_add per primitive) instead of
     // letting the compiler hold it in an SGPR and copy it out twice per primitive; global reads want it uniform (scalar loads)
     if (LDS) asm volatile("" : "+v"(q));
-    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
     int4 run = runs[0];
     for (int r = 0; r < n_runs; ++r) {
         const int type = run.x, count = run.z;
@@ -223,6 +222,15 @@ __device__ __forceinline__ uint32_t closest_hit_slots(const SceneMem<LDS> M, con
             }
         }
     }
+}
+// The whole scene in one go: q = SceneMem address of the first slot.  Returns the address of the winning slot (0 = miss:
+// address 0 is the runs section, or the first bytes of LDS, never a slot) and its distance.
+template <bool LDS>
+__device__ __forceinline__ uint32_t closest_hit_slots(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
+                                                      f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {
+    uint32_t best = 0U;
+    float closest = tmax;
+    closest_hit_runs<LDS>(M, runs, n_runs, q, o, d, F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)), tmin, tminp, closest, best);
     t_out = closest;
     return best;
 }

@@ -28,6 +28,9 @@ def load_png_rgb(name):
 @pytest.fixture(scope="session")
 def ctx():
     """One rt_ctx for the whole GPU session (the library is the thing under test; no fallback)."""
+    # Some tests hand torch device buffers to the library.  PyTorch ships its own libamdhip64; whichever HIP runtime is
+    # loaded first serves the whole process, and torch only finds the GPU through its own, so torch goes first.
+    import torch  # noqa: F401
     from rtamd import lib
     c = lib.Context()
     yield c

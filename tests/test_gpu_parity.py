@@ -182,9 +182,10 @@ def test_boxes_path(ctx):
     assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=1e-2)
 
 
-def test_stress_scene_reduced_global_memory_path(ctx):
-    """SURVEY.md 8(d) config 5 at reduced counts (600 spheres, 12x12x2 triangles): the flattened scene no longer
-    fits the 48 KB LDS staging limit, so the kernel reads it from global memory (scalar loads) - same results."""
+def test_stress_scene_reduced_tiled_kernel(ctx):
+    """SURVEY.md 8(d) config 5 at reduced counts (600 spheres, 12x12x2 triangles): the flattened scene no longer fits
+    the 48 KB whole-scene LDS limit, so k_path_tiled walks it through LDS in 16 KB pieces - same results as the oracle,
+    and bit-identical to the plain global-memory kernel (debug flag 2)."""
     s, cam, prm = scenes.scene_stress(n_spheres=600, grid=12, spp=4, seed=3)
     assert len(s.prims) == 600 + 1 + 288 + 1
     g = ctx.render_path(s, cam, prm, 96, 54)
@@ -193,6 +194,17 @@ def test_stress_scene_reduced_global_memory_path(ctx):
     assert abs(g["rays"] - o["rays"]) <= 5e-3 * o["rays"]
     assert frac_within(g["rgb"], om, 1e-3) >= 0.97
     assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=2e-2)
+    ctx.set_debug_flags(2)
+    try:
+        b = ctx.render_path(s, cam, prm, 96, 54)
+    finally:
+        ctx.set_debug_flags(0)
+    assert g["rays"] == b["rays"] and np.array_equal(g["rgb"], b["rgb"])
+    # image sizes that leave waves and whole blocks partly or wholly outside the frame (block-wide barriers must still match)
+    for (w, h) in [(1, 1), (17, 33), (70, 20)]:
+        g = ctx.render_path(s, cam, prm, w, h)
+        o = oracle.render_path(s, cam, prm, w, h)
+        assert abs(g["rays"] - o["rays"]) <= max(2, 2e-2 * o["rays"]) and g["samples"] == w * h * 4
 
 
 def test_lds_and_global_scene_paths_agree(ctx):
