@@ -91,6 +91,15 @@ __global__ __launch_bounds__(256) void k_pkfma(float* out, float a, float b) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// overlap probes: a transcendental / compare next to independent cheap VOP2 work (is the cost additive?)
+KERNEL(k_sqrt_fmac3, float x[CHAINS]; float y[CHAINS]; for (int c = 0; c < CHAINS; ++c) { x[c] = threadIdx.x + c + 1; y[c] = c; }, asm volatile("v_sqrt_f32 %0, %0\n\tv_fmac_f32 %1, %2, %3\n\tv_fmac_f32 %1, %3, %2\n\tv_fmac_f32 %1, %2, %2" : "+v"(x[c]), "+v"(y[c]) : "v"(a), "v"(b)))
+KERNEL(k_cmp_fmac2, float x[CHAINS]; float y[CHAINS]; for (int c = 0; c < CHAINS; ++c) { x[c] = threadIdx.x + c + 1; y[c] = c; }, asm volatile("v_cmp_lt_f32 vcc, %0, %2\n\tv_fmac_f32 %1, %2, %3\n\tv_fmac_f32 %1, %3, %2" : "+v"(x[c]), "+v"(y[c]) : "v"(a), "v"(b) : "vcc"))
+KERNEL(k_mul_lit, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mul_f32 %0, 0x3f8ccccd, %0" : "+v"(x[c])))
+KERNEL(k_cmp_u32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cmp_le_u32 vcc, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a)) : "vcc"))
+KERNEL(k_min_u32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_min_u32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_and_or, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
+KERNEL(k_dsread, float x[CHAINS]; __shared__ float4 sm[64]; if (threadIdx.x < 64) sm[threadIdx.x] = make_float4(a, b, a, b); __syncthreads(); unsigned ad = (unsigned)(uintptr_t)sm & 0xffffu; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, { float4 v; asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ad)); x[c] += v.x; })
+
 template <typename K>
 void run(const char* name, K k, float* d, double ops_per_instr) {
     int blocks = 256 * 8;
@@ -120,6 +129,8 @@ int main() {
     run("v_fma const", k_fma_k, d, 2); run("v_max_f32", k_max, d, 1); run("v_cmp sgpr", k_cmp_s, d, 1); run("v_cmp_e64->s", k_cmp64, d, 1);
     run("v_cmp_class", k_cmpx, d, 1); run("v_and_b32", k_and, d, 1); run("v_bfi_b32", k_bfi, d, 1); run("v_add_u32", k_addu, d, 1); run("v_lshl_add_u32", k_lshladd, d, 1);
     run("v_pk_mul_f32", k_pkmul, d, 2); run("v_pk_add_f32", k_pkadd, d, 2);
+    run("sqrt+3fmac", k_sqrt_fmac3, d, 7); run("cmp+2fmac", k_cmp_fmac2, d, 5); run("v_mul literal", k_mul_lit, d, 1); run("v_cmp_le_u32", k_cmp_u32, d, 1);
+    run("v_min_u32", k_min_u32, d, 1); run("v_and_or_b32", k_and_or, d, 1); run("ds_read_b128 same addr (+add)", k_dsread, d, 1);
     hipLaunchKernelGGL(k_clock, dim3(2048), dim3(256), 0, 0, d, 1.0001f, 0.5f); hipDeviceSynchronize();
     hipFree(d);
     return 0;
