@@ -40,7 +40,7 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_pending = false;
     DevBuf scene_buf, partial, accum, bgra, rgb;
-    unsigned long long* d_counters = nullptr;     // [0] rays, [1] shadow rays
+    unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
     unsigned long long* h_counters = nullptr;     // pinned
     void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned scene staging
     uint64_t pending_samples = 0;
@@ -293,13 +293,13 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
 }
 
 int begin_timed(rt_ctx* c, hipStream_t st) {
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
     return RT_OK;
 }
 int end_timed(rt_ctx* c, hipStream_t st) {
     HIPCHK(c, hipEventRecord(c->ev1, st));
-    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, RT_COUNTER_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     c->timing_pending = true;
     return RT_OK;
 }
@@ -342,10 +342,10 @@ rt_ctx* rt_create(int32_t device_id) {
     rt_ctx* c = new rt_ctx();
     c->device = dev;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
-              hipEventCreate(&c->ev1) == hipSuccess && hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)) == hipSuccess &&
-              hipHostMalloc((void**)&c->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+              hipEventCreate(&c->ev1) == hipSuccess && hipMalloc((void**)&c->d_counters, RT_COUNTER_WORDS * sizeof(unsigned long long)) == hipSuccess &&
+              hipHostMalloc((void**)&c->h_counters, RT_COUNTER_WORDS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
     if (!ok) { g_create_error = "failed to create stream/events/counters"; rt_destroy(c); return nullptr; }
-    memset(c->h_counters, 0, 4 * sizeof(unsigned long long));
+    memset(c->h_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long));
     return c;
 }
 
@@ -391,7 +391,8 @@ int32_t rt_sync(rt_ctx* c, void* stream) {
         float ms = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->stats.kernel_ms = ms;
-        c->stats.rays = c->h_counters[0]; c->stats.shadow_rays = c->h_counters[1];
+        c->stats.rays = c->stats.shadow_rays = 0;   // the kernels spread their atomics over RT_COUNTER_BANKS banks
+        for (int b = 0; b < RT_COUNTER_BANKS; ++b) { c->stats.rays += c->h_counters[2 * b]; c->stats.shadow_rays += c->h_counters[2 * b + 1]; }
         c->stats.samples = c->pending_samples;
         c->timing_pending = false;
     }

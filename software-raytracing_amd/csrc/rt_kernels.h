@@ -9,6 +9,11 @@
 namespace rt {
 struct DevScene;
 
+// Ray counters: one 64-bit atomic per wave and counter; 130k waves hitting ONE address cost ~3 ms at 4K (the whole 01
+// frame takes less), so the atomics are spread over banks (bank = block index mod RT_COUNTER_BANKS), summed on the host.
+#define RT_COUNTER_BANKS 256
+#define RT_COUNTER_WORDS (2 * RT_COUNTER_BANKS)
+
 struct PathArgs {
     int width, height;
     int sample_begin, sample_end;   // samples [begin,end) of every pixel

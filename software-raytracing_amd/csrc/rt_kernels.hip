@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
         // debug flag 4: report the lane's scene-query count in w instead of its sample count (parity diagnostics)
         out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);
     }
-    wave_add_u64(counters + 0, L.rays);
+    wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
 }
 
 // Large scenes (blob > 48 KB): the slot section is walked in pieces of <= RT_TILE_BYTES that the block's four waves
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_path_tiled(DevScene SD, PathArgs A, flo
         }
     }
     if (inside) out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);
-    wave_add_u64(counters + 0, L.rays);
+    wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
 }
 
 template <int VARIANT>
@@ -278,7 +278,10 @@ void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* o
 template <bool SOFT>
 __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     const Scn S = scn_over(SD, SD.blob);
-    __shared__ float stk[RT_WHITTED_MAX_DEPTH_LIMIT + 1][8][WBLOCK];   // slot k: o(3) d(3) weight node
+    // slot k (k = depth of the parked child, 1..max_depth+1): o(3) d(3) weight node, one column per thread; sized by the
+    // launch to max_depth + 2 slots (4 KB each), so the default depth 4 leaves room for 6 blocks per CU
+    extern __shared__ float stk_raw[];
+    float (*stk)[8][WBLOCK] = reinterpret_cast<float (*)[8][WBLOCK]>(stk_raw);
     const int tid = threadIdx.x;
     // 16x8 pixels per 128-thread block, 8x8 per wave
     int tiles_x = (A.width + 15) >> 4;
@@ -384,14 +387,15 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene SD, WhittedArgs A, 
         }
     }
     if (inside) out[pixel] = make_float4(acc.x, acc.y, acc.z, 1.0f);
-    wave_add_u64(counters + 0, rays);
-    wave_add_u64(counters + 1, srays);
+    wave_add_u64(counters + 2 * (blockIdx.x % RT_COUNTER_BANKS), rays);
+    wave_add_u64(counters + 2 * (blockIdx.x % RT_COUNTER_BANKS) + 1, srays);
 }
 
 void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 7) / 8));
-    if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), 0, st, S, A, out, counters);
-    else      hipLaunchKernelGGL(k_whitted<false>, grid, dim3(WBLOCK), 0, st, S, A, out, counters);
+    size_t stack_bytes = (size_t)(A.max_depth + 2) * 8 * WBLOCK * sizeof(float);
+    if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), stack_bytes, st, S, A, out, counters);
+    else      hipLaunchKernelGGL(k_whitted<false>, grid, dim3(WBLOCK), stack_bytes, st, S, A, out, counters);
 }
 
 // =================================================================================================
