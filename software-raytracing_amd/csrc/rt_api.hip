@@ -68,8 +68,11 @@ void rotation_mat(const float deg[3], float out[9]) {
 }
 
 struct HostScene {
-    std::vector<int4> runs, info;
+    std::vector<int4> runs, info;         // Whitted scenes: the IEEE-exact layout of rt_strict.h
+    std::vector<int4> sruns;              // slot layout: runs over 'slots' (all path queries; 02's shadow samples)
     std::vector<float4> geom, mats, lights;
+    bool path = false;
+    bool whitted_branches = false;
     std::vector<float4> slots;            // path scenes (variant 3/4): the slot section of rt_device.h
     std::vector<size_t> slot_mat_fixups;  // indices into slots of the B records; B.w holds the material index until upload
     std::vector<int4> chunks;             // path scenes: {first slot byte offset (in the slot section), bytes, first run, n runs}
@@ -80,9 +83,9 @@ struct HostScene {
         const int bytes = (int)(n_f4 * 16);
         const int start = (int)(slots.size() * 16) - bytes;
         bool new_chunk = chunks.empty() || chunks.back().y + bytes > RT_TILE_BYTES;
-        if (new_chunk) chunks.push_back(make_int4(start, 0, (int)runs.size(), 0));
-        if (!new_chunk && !runs.empty() && runs.back().x == dtype) runs.back().z++;
-        else { runs.push_back(make_int4(dtype, 0, 1, prim)); chunks.back().w++; }
+        if (new_chunk) chunks.push_back(make_int4(start, 0, (int)sruns.size(), 0));
+        if (!new_chunk && !sruns.empty() && sruns.back().x == dtype) sruns.back().z++;
+        else { sruns.push_back(make_int4(dtype, 0, 1, prim)); chunks.back().w++; }
         chunks.back().y += bytes;
     }
 };
@@ -117,6 +120,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         if (variant != 0 && type == MAT_PHONG) return fail(c, RT_ERR_UNSUPPORTED, "path render cannot shade RT_MAT_PHONG (material " + std::to_string(m) + ")");
         m0.w = __builtin_bit_cast(float, type);
         H.mats.push_back(m0); H.mats.push_back(m1); H.mats.push_back(m2);
+        if (type == MAT_PHONG && M.primary_to_secondary < 1.0f && M.reflect_to_refract > 0.0f && M.reflect_to_refract < 1.0f) H.whitted_branches = true;
     }
     // material slot n_materials: "no material".  Whitted: SceneElement's default (01 Types.h:51-58); path: black (04 Main.cpp:489-492)
     {
@@ -130,7 +134,10 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         int gi = (int)H.geom.size();
         int dtype = P.type;
         const float* f = P.f;
-        if (variant != 0) {   // path scenes: slot layout (rt_device.h)
+        if (variant == 0 && (P.type == RT_PRIM_RECT || P.type == RT_PRIM_BOX))
+            return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles and boxes exist only in the path-tracing examples");
+        H.path = variant != 0;
+        {   // slot layout (rt_device.h): every query of the path scenes; the shadow samples of 02
             float4 G = f4(0, 0, 0, 0), A = f4(0, 0, 0, 0), B = f4(0, 0, 0, 0), C = f4(0, 0, 0, 0), G1 = G, G2 = G, G3 = G;
             bool wide = false;
             switch (P.type) {
@@ -204,7 +211,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
                     H.add_slot(PRIM_RECT, 8, i);
                 }
                 H.info.push_back(make_int4(PRIM_RECT, 0, mat, (int)P.flags));
-                continue; }
+                continue; }   // boxes: path scenes only
             default: return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": unknown type " + std::to_string(P.type));
             }
             B.w = __builtin_bit_cast(float, mat);
@@ -212,15 +219,13 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
             if (wide) { H.slots.push_back(G1); H.slots.push_back(G2); H.slots.push_back(G3); H.slots.push_back(f4(0, 0, 0, 0)); }
             // rectangles and triangles share one loop in the kernel but not one run: the run type picks the inside test
             H.add_slot(dtype, wide ? 8 : 4, i);
-            H.info.push_back(make_int4(dtype, 0, mat, (int)P.flags));
-            continue;
+            if (variant != 0) { H.info.push_back(make_int4(dtype, 0, mat, (int)P.flags)); continue; }
+            dtype = P.type;
         }
         switch (P.type) {
         // Whitted scenes (01/02): the IEEE-exact layout of rt_strict.h
         case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], f[3])); break;
         case RT_PRIM_PLANE: H.geom.push_back(f4(f[3], f[4], f[5], 0)); H.geom.push_back(f4(f[0], f[1], f[2], 0)); break;   // n, p0
-        case RT_PRIM_RECT: case RT_PRIM_BOX:
-            return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": rectangles and boxes exist only in the path-tracing examples");
         case RT_PRIM_TRIANGLE: {
             float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
             float n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};   // cross(e2,e1), Ray.hpp:159
@@ -253,8 +258,8 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
 int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
     // one spare zero record after the runs: the path kernels prefetch runs[r + 1]
-    size_t o_runs = 0, o_chunks = pad(o_runs + (H.runs.size() + 1) * 16), o_geom = pad(o_chunks + H.chunks.size() * 16), o_info = pad(o_geom + H.geom.size() * 16),
-           o_slots = pad(o_info + (H.slots.empty() ? H.info.size() : 0) * 16), o_mats = pad(o_slots + H.slots.size() * 16),
+    size_t o_runs = 0, o_sruns = pad(o_runs + (H.runs.size() + 1) * 16), o_chunks = pad(o_sruns + (H.sruns.size() + 1) * 16), o_geom = pad(o_chunks + H.chunks.size() * 16), o_info = pad(o_geom + H.geom.size() * 16),
+           o_slots = pad(o_info + (H.path ? 0 : H.info.size()) * 16), o_mats = pad(o_slots + H.slots.size() * 16),
            o_lights = pad(o_mats + H.mats.size() * 16), total = pad(o_lights + H.lights.size() * 16 + 16);
     if (total > c->h_stage_cap) {
         if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
@@ -267,13 +272,13 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     HIPCHK(c, hipStreamSynchronize(st));
     char* h = (char*)c->h_stage;
     memset(h, 0, o_geom);
-    memcpy(h + o_runs, H.runs.data(), H.runs.size() * 16);
+    memcpy(h + o_runs, H.runs.data(), H.runs.size() * 16); memcpy(h + o_sruns, H.sruns.data(), H.sruns.size() * 16);
     for (size_t k = 0; k < H.chunks.size(); ++k) {   // slot-section offsets -> blob byte offsets
         int4 ch = H.chunks[k]; ch.x += (int)o_slots;
         memcpy(h + o_chunks + k * 16, &ch, 16);
     }
     memcpy(h + o_geom, H.geom.data(), H.geom.size() * 16);
-    if (H.slots.empty()) memcpy(h + o_info, H.info.data(), H.info.size() * 16);
+    if (!H.path) memcpy(h + o_info, H.info.data(), H.info.size() * 16);
     memcpy(h + o_slots, H.slots.data(), H.slots.size() * 16);
     for (size_t b : H.slot_mat_fixups) {   // material index -> byte offset of its record in the blob
         float4* B = reinterpret_cast<float4*>(h + o_slots) + b;
@@ -289,6 +294,13 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     D.n_runs = (int)H.runs.size(); D.n_prims = (int)H.info.size(); D.n_mats = (int)H.mats.size() / 3; D.n_lights = (int)H.lights.size() / 2;
     D.has_aa = H.has_aa; D.off_slots = (int)(o_slots / 16);
     D.off_chunks = (int)(o_chunks / 16); D.n_chunks = (int)H.chunks.size();
+    D.whitted_branches = H.whitted_branches;
+    D.srun_pack[0] = D.srun_pack[1] = 0ULL; D.srun_packed = H.sruns.size() <= 8;
+    for (size_t r = 0; r < H.sruns.size() && r < 8; ++r) {
+        if (H.sruns[r].z > 8191) D.srun_packed = 0;
+        D.srun_pack[r / 4] |= (unsigned long long)(((uint32_t)H.sruns[r].x | ((uint32_t)H.sruns[r].z << 3)) & 0xFFFFU) << ((r % 4) * 16);
+    }
+    D.off_sruns = (int)(o_sruns / 16); D.n_sruns = (int)H.sruns.size(); D.slot_bytes = (int)(H.slots.size() * 16);
     return RT_OK;
 }
 

@@ -30,6 +30,10 @@ struct DevScene {
     int n_runs, n_prims, n_mats, n_lights;
     int has_aa;     // any axis-aligned plane run
     int off_slots;  // path scenes: float4 offset of the slot section (see "slot layout" below); geom/info unused there
+    unsigned long long srun_pack[2];      // the first 8 slot runs as (type | count << 3), 16 bits each; srun_packed = all of them fit
+    int srun_packed;
+    int whitted_branches;                 // Whitted scenes: some material spawns reflection AND refraction at one hit (needs the LDS stack)
+    int off_sruns, n_sruns, slot_bytes;   // the runs over the slot section (the 'runs' above belong to the Whitted layout)
     int off_chunks, n_chunks;   // path scenes: int4 {blob byte offset, bytes, first run, n runs} per <= RT_TILE_BYTES piece of the slots
 };
 
@@ -156,16 +160,25 @@ template <bool LDS> struct SceneMem {
 // closest_hit_runs walks n_runs runs whose first slot is at SceneMem address q and updates (closest, best) in place, so a
 // scene can be walked in pieces (k_path_tiled).
 // All traced directions are unit vectors (Ray's constructor normalises), so a = d.d = 1 in the sphere test.
-template <bool LDS>
+// PACKED: the run descriptors come from two 64-bit kernel-argument words (16 bits each: type | count << 3, at most 8 runs)
+// instead of scalar loads: no memory latency per run, which matters where few waves are resident (k_whitted).
+template <bool LDS, bool PACKED = false>
 __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
-                                                 f3 o, f3 d, f3 inv_d, float tmin, float tminp, float& closest, uint32_t& best) {
+                                                 f3 o, f3 d, f3 inv_d, float tmin, float tminp, float& closest, uint32_t& best,
+                                                 unsigned long long pack0 = 0ULL, unsigned long long pack1 = 0ULL) {
     // LDS addresses are VGPR operands of ds_read anyway: keep the cursor in a VGPR (one v_add per primitive) instead of
     // letting the compiler hold it in an SGPR and copy it out twice per primitive; global reads want it uniform (scalar loads)
     if (LDS) asm volatile("" : "+v"(q));
-    int4 run = runs[0];
+    int4 run = PACKED ? make_int4(0, 0, 0, 0) : runs[0];
     for (int r = 0; r < n_runs; ++r) {
-        const int type = run.x, count = run.z;
-        run = runs[r + 1];     // prefetch (the section is padded by one record)
+        int type, count;
+        if (PACKED) {
+            const uint32_t desc = (uint32_t)((r < 4 ? pack0 : pack1) >> ((r & 3) * 16)) & 0xFFFFU;
+            type = (int)(desc & 7U); count = (int)(desc >> 3);
+        } else {
+            type = run.x; count = run.z;
+            run = runs[r + 1];     // prefetch (the section is padded by one record)
+        }
         if (LDS) asm volatile("" : "+v"(q), "+v"(best), "+v"(closest));   // one definition point per run for the carried values
         if (type == PRIM_SPHERE) {
             // Ray::intersectsSphere (Common/Ray.hpp:94-137).  Roots t1 <= t2; "a root below tMin becomes tMax" (:127-128):

@@ -33,6 +33,7 @@ struct WhittedArgs {
     int width, height, max_depth, shadow_samples;
     uint32_t seed;
     float w, h, tan_half;           // float(width), float(height), tanf(fovRadians/2) (01 Main.cpp:329-341)
+    int stack_bytes, shadow_lds;    // set by launch_whitted: LDS bytes of the recursion stack; slot layout staged behind it for 02's shadow samples
 };
 
 void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st);

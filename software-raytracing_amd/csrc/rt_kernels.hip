@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
         __syncthreads();
         base = reinterpret_cast<const char*>(smem);
     }
-    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_runs);   // always global: scalar loads
+    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);   // always global: scalar loads
     const SceneMem<LDS> M{base};
     const uint32_t slots0 = M.at((uint32_t)SD.off_slots * 16U), mats0 = M.at(0U);
     int px, py;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
             // TraceTay: one scene query (03 Main.cpp:392, 04 Main.cpp:447)
             ++L.rays;
             float t;
-            uint32_t hit = closest_hit_slots<LDS>(M, runs, SD.n_runs, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+            uint32_t hit = closest_hit_slots<LDS>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
             shade<VARIANT, LDS>(M, A, mats0, hit, t, L);
         }
     }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* _
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_path_tiled(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 smem[];
-    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_runs);
+    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
     const int4* __restrict__ chunks = reinterpret_cast<const int4*>(SD.blob + SD.off_chunks);
     const SceneMem<false> G{reinterpret_cast<const char*>(SD.blob)};
     const SceneMem<true> T{reinterpret_cast<const char*>(smem)};
@@ -276,12 +276,26 @@ void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* o
 // =================================================================================================
 #define WBLOCK 128
 template <bool SOFT>
-__global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+// 8 waves/SIMD (64 VGPRs, a few cold values spilled): this kernel is bound by dependent-issue latency, not registers:
+// measured 02 4K/256 samples 10.5 ms at 4 waves, 9.3 at 5, 8.7 at 6, 8.3 at 8
+__global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     const Scn S = scn_over(SD, SD.blob);
     // slot k (k = depth of the parked child, 1..max_depth+1): o(3) d(3) weight node, one column per thread; sized by the
     // launch to max_depth + 2 slots (4 KB each), so the default depth 4 leaves room for 6 blocks per CU
     extern __shared__ float stk_raw[];
     float (*stk)[8][WBLOCK] = reinterpret_cast<float (*)[8][WBLOCK]>(stk_raw);
+    // 02: the shadow samples (almost all of its rays) run on the slot layout staged in LDS behind the stack, with the
+    // fast tests of the path kernels (see fastshadow in rt_strict.h for why that is safe); A.shadow_lds = 0 when the
+    // scene is too large for that
+    const SceneMem<true> T{reinterpret_cast<const char*>(stk_raw)};
+    const uint32_t sh_slots = T.at((uint32_t)A.stack_bytes);
+    const int4* __restrict__ sruns = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
+    if (SOFT && A.shadow_lds) {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(stk_raw) + A.stack_bytes);
+        const float4* src = SD.blob + SD.off_slots;
+        for (int i = threadIdx.x; i < (SD.slot_bytes >> 4); i += WBLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
     const int tid = threadIdx.x;
     // 16x8 pixels per 128-thread block, 8x8 per wave
     int tiles_x = (A.width + 15) >> 4;
@@ -333,9 +347,15 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene SD, WhittedArgs A, 
                                 uint32_t c = ((node * (uint32_t)S.n_lights + (uint32_t)li) * (uint32_t)A.shadow_samples + (uint32_t)i) * 4U;
                                 float u0, u1, u2, u3;
                                 rng_pair(skey, c, u0, u1); rng_pair(skey, c + 2U, u2, u3);
-                                f3 sd = strict::to_light_disk(p, lp, l0.w, u0, u1, u2, u3);
+                                f3 sd = fastshadow::to_light_disk(p, lp, tod, l0.w, u0, u1, u2, u3);
                                 ++srays;
-                                if (strict::any_hit(S, p, sd, 0.01f, tmax_s)) intensity -= per;
+                                bool occluded;
+                                if (A.shadow_lds) {
+                                    float closest = tmax_s; uint32_t best = 0U;
+                                    closest_hit_runs<true, true>(T, sruns, SD.n_sruns, sh_slots, p, sd, F3(rcp_fast(sd.x), rcp_fast(sd.y), rcp_fast(sd.z)), 0.01f, 0.01f, closest, best, SD.srun_pack[0], SD.srun_pack[1]);
+                                    occluded = best != 0U;
+                                } else occluded = fastshadow::any_hit(S, p, sd, 0.01f, tmax_s);
+                                if (occluded) intensity -= per;
                             }
                         }
                         if (skip) continue;   // 01: an occluded light is skipped entirely
@@ -393,9 +413,14 @@ __global__ __launch_bounds__(WBLOCK) void k_whitted(DevScene SD, WhittedArgs A, 
 
 void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 7) / 8));
-    size_t stack_bytes = (size_t)(A.max_depth + 2) * 8 * WBLOCK * sizeof(float);
-    if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), stack_bytes, st, S, A, out, counters);
-    else      hipLaunchKernelGGL(k_whitted<false>, grid, dim3(WBLOCK), stack_bytes, st, S, A, out, counters);
+    WhittedArgs B = A;
+    // the stack only ever holds the refraction child of a hit that ALSO reflects (0 < reflectToRefract < 1 on a material with
+    // primaryToSecondary < 1): none of the reference's scenes has one, and then no LDS is spent on it (more blocks per CU)
+    B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : 0;
+    B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed;
+    size_t lds = (size_t)B.stack_bytes + (B.shadow_lds ? (size_t)S.slot_bytes + 256 : 0);   // + one slot of slack for the read-ahead of wide slots
+    if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
+    else      hipLaunchKernelGGL(k_whitted<false>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
 }
 
 // =================================================================================================

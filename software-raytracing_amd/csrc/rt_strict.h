@@ -139,3 +139,48 @@ static __device__ __forceinline__ f3 to_light_disk(f3 p, f3 lp, float radius, fl
 } // namespace rt
 
 #pragma clang fp contract(fast)
+
+namespace rt {
+// 02's shadow samples (MAX_SHADOW_SAMPLES per shaded hit, 02 Main.cpp:452-467) are the one place of the Whitted kernels
+// where the fast forms are used: a sample only moves the pixel by 1/samples of one light's contribution and its
+// direction is random anyway, so a last-bit difference in it cannot create the systematic edge errors that made the
+// closest-hit arithmetic exact; the ray COUNT does not depend on the outcome at all.  Same layout as strict::any_hit.
+struct fastshadow {
+static __device__ __forceinline__ bool any_hit(const Scn& S, f3 o, f3 d, float tmin, float tmax) {
+    bool hit = false;
+    for (int r = 0; r < S.n_runs; ++r) {
+        int4 run = S.runs[r];
+        const float4* g = S.geom + run.y;
+        if (run.x == PRIM_SPHERE) {
+            for (int i = 0; i < run.z; ++i) {   // Ray::intersectsSphere with a = d.d = 1: roots b -+ s
+                float4 q = g[i];
+                f3 co = F3(q) - o;
+                float b = dot(d, co);
+                float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, -q.w * q.w)));
+                float s = sqrt_fast(fmaf(b, b, -c));
+                float t1 = b - s, t2 = b + s;
+                bool nb = t1 < tmin;
+                float tc = nb ? t2 : t1;
+                hit |= (tc >= tmin) & (nb | (tc <= tmax));
+            }
+        } else if (run.x == PRIM_PLANE) {
+            for (int i = 0; i < run.z; ++i) {
+                f3 n = F3(g[2 * i]), p0 = F3(g[2 * i + 1]);
+                float t = dot(n, p0 - o) * rcp_fast(dot(d, n));
+                hit |= (t > 0.0f) & (t >= tmin) & (t <= tmax);
+            }
+        } else if (run.x == PRIM_TRI) {
+            for (int i = 0; i < run.z; ++i) { float t; hit |= strict::hit_tri(g + 4 * i, o, d, tmin, tmax, t); }
+        }
+    }
+    return hit;
+}
+// RandomVectorToLightSphere (02 Main.cpp:539-566); 'to' = normalize(lp - p) is the same for every sample of a light
+static __device__ __forceinline__ f3 to_light_disk(f3 p, f3 lp, f3 to, float radius, float u0, float u1, float u2, float u3) {
+    f3 vb = F3(fmaf(2.0f, u0, -1.0f), fmaf(2.0f, u1, -1.0f), fmaf(2.0f, u2, -1.0f));
+    f3 pl = normalize(cross(to, to + vb));
+    f3 target = madd(pl, radius * u3, lp);
+    return normalize(target - p);
+}
+};
+} // namespace rt
