@@ -12,6 +12,7 @@
 #include <vector>
 #include "rt_device.h"
 #include "rt_kernels.h"
+#include "rt_jit.h"
 
 using namespace rt;
 
@@ -42,6 +43,8 @@ struct rt_ctx {
     DevBuf scene_buf, partial, accum, bgra, rgb;
     unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
     unsigned long long* h_counters = nullptr;     // pinned
+    std::string jit_note;                         // why the last path render was not scene-specialised ("" = it was)
+    int last_path_kernel = -1;                    // 2 specialised, 1 generic LDS-resident, 0 tiled / global
     void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned scene staging
     uint64_t pending_samples = 0;
     rt_stats stats{};
@@ -445,7 +448,14 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     float4* target = (float4*)d_accum;
     if (slices > 1) { HIPCHK(c, c->partial.reserve(npx * slices * sizeof(float4))); target = (float4*)c->partial.p; }
     if ((rc = begin_timed(c, st))) return rc;
-    launch_path(p->variant, D, A, target, slices, c->d_counters, st);
+    // small scenes: the scene query compiled for THIS scene (literal operands, no loops); debug flag 8 or RT_MI355_JIT=0 keeps
+    // the generic kernel (A/B and parity tests); an unavailable hiprtc is not an error, the generic kernel renders the same image
+    hipFunction_t jit = nullptr;
+    const char* jit_env = getenv("RT_MI355_JIT");
+    if (!(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES)
+        jit = jit_path_kernel(p->variant, H.slots, H.sruns, c->jit_note);
+    c->last_path_kernel = jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0);
+    launch_path(p->variant, D, A, target, slices, c->d_counters, st, jit);
     HIPCHK(c, hipGetLastError());
     if (slices > 1) { launch_sum_slices((const float4*)c->partial.p, (int)npx, slices, (float4*)d_accum, st); HIPCHK(c, hipGetLastError()); }
     c->pending_samples = (uint64_t)npx * (uint64_t)n_samples;
@@ -526,6 +536,23 @@ int32_t rt_render_path(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, c
 }
 
 // test/bench hook: regeneration threshold (idle lanes per wave); <0 restores the default. Not part of rt_mi355.h.
+// Diagnostics (not in rt_mi355.h).  rt_debug_last_path_kernel: which kernel rendered the last path image (2 scene-specialised,
+// 1 generic LDS-resident, 0 tiled / global) and, when not specialised, why.  rt_debug_jit_probe: builds the specialised
+// kernel source for a scene and compiles it (no GPU needed for the compile; loading the module needs one).
+int32_t rt_debug_last_path_kernel(const rt_ctx* c, char* note, int32_t cap) {
+    if (!c) return -1;
+    if (note && cap > 0) { strncpy(note, c->jit_note.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
+    return c->last_path_kernel;
+}
+int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, int32_t cap) {
+    HostScene H;
+    int rc = compile_scene(nullptr, scene, variant, H);
+    if (rc) return rc;
+    std::string n;
+    hipFunction_t fn = jit_path_kernel(variant, H.slots, H.sruns, n);
+    if (note && cap > 0) { strncpy(note, n.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
+    return fn ? 1 : 0;
+}
 int32_t rt_debug_set_flags(rt_ctx* c, int32_t f) { if (!c) return RT_ERR_BAD_ARG; c->debug_flags = f; return RT_OK; }
 int32_t rt_debug_set_regen_threshold(rt_ctx* c, int32_t n) { if (!c) return RT_ERR_BAD_ARG; c->regen_threshold_override = n; return RT_OK; }
 

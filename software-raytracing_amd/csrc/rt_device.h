@@ -1,8 +1,10 @@
 // rt_device.h - device-side scene layout and the small float3 toolkit shared by the kernels.
 // gfx950 only.  Reference semantics cited per function (paths relative to /root/reference/Sources).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace rt {
 

@@ -1,0 +1,11 @@
+// rt_jit.h - scene-specialised path kernels (hiprtc).  See rt_jit.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+namespace rt {
+// Returns the kernel for this (variant, slot section) or nullptr when specialisation is unavailable (hiprtc missing, compile
+// error, scene too large); 'note' then says why.  Compiled kernels are cached per process by the hash of their source.
+hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, std::string& note);
+}

@@ -1,0 +1,126 @@
+// rt_jit.hip - scene-specialised build of k_path<VARIANT, true> for small scenes.
+//
+// On gfx950 a VALU instruction reads a 32-bit LITERAL at full rate but an SGPR operand at half rate
+// (profiles/r01_valu_issue_rates_ubench.txt), and the generic closest-hit loop spends about a fifth of its VALU work on
+// what a fixed scene does not need: run dispatch, cursor arithmetic, loop-carried copies, LDS reads of primitive records.
+// So for a scene of up to RT_JIT_MAX_PRIMS primitives the scene query is GENERATED as straight-line code, one block per
+// primitive in scene order with the primitive's numbers as literals - the same arithmetic, operation for operation, as the
+// loops of closest_hit_runs (rt_device.h) - and compiled with hiprtc together with the unchanged shading / regeneration
+// code (rt_path_device.h, embedded as text).  Shading still reads the winner's slot from the LDS-staged blob.
+#include "rt_jit.h"
+#include "rt_device.h"
+#include <hip/hiprtc.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+namespace rt {
+namespace {
+const char* const kSrcArgs =
+#include "rt_jit_src_args.inc"
+    ;
+const char* const kSrcDevice =
+#include "rt_jit_src_device.inc"
+    ;
+const char* const kSrcPath =
+#include "rt_jit_src_path.inc"
+    ;
+
+constexpr int RT_JIT_MAX_PRIMS = 64;
+
+std::string lit(float v) {   // exact: hexadecimal floating literal
+    if (std::isinf(v)) return v > 0 ? "__builtin_inff()" : "(-__builtin_inff())";
+    if (std::isnan(v)) return "__builtin_nanf(\"\")";
+    char b[64];
+    snprintf(b, sizeof b, "%af", (double)v);
+    return b;
+}
+std::string v3(const float4& g) { return "F3(" + lit(g.x) + ", " + lit(g.y) + ", " + lit(g.z) + ")"; }
+
+// One block per primitive; K = byte offset of its slot in the slot section + SLOT_BYTES (0 stays "no hit").
+std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<int4>& sruns) {
+    std::string s;
+    s += "namespace rt {\n__device__ __forceinline__ uint32_t closest_hit_jit(f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {\n";
+    s += "    uint32_t best = 0U;\n    float closest = tmax;\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d; (void)tmin; (void)tminp;\n";
+    size_t q = 0;   // float4 index into slots
+    for (const int4& run : sruns) {
+        for (int i = 0; i < run.z; ++i) {
+            const float4* g = &slots[q];
+            const std::string K = std::to_string(q * 16 + SLOT_BYTES) + "U";
+            const std::string take = "closest = hit ? t : closest; best = hit ? " + K + " : best; }\n";
+            if (run.x == PRIM_SPHERE) {
+                s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
+                s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
+                s += "      float s = sqrt_fast(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;\n";
+                s += "      bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; bool ge = tc >= tmin, le = tc <= closest;\n";
+                s += "      closest = (ge & le) ? tc : closest; best = (ge & (near_behind | le)) ? " + K + " : best; }\n";
+            } else if (run.x >= PRIM_AAPLANE_X) {
+                const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
+                s += "    { float t = (" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + "; bool hit = (t >= tminp) & (t <= closest); " + take;
+            } else if (run.x == PRIM_PLANE) {
+                s += "    { float t = (" + lit(g[0].w) + " - dot(" + v3(g[0]) + ", o)) * rcp_fast(dot(" + v3(g[0]) + ", d)); bool hit = (t >= tminp) & (t <= closest); " + take;
+            } else {   // rectangle / triangle: wide slot, G1..G3 behind the shading records
+                const float4 &g1 = g[4], &g2 = g[5], &g3 = g[6];
+                s += "    { float t = (" + lit(g[0].w) + " - dot(" + v3(g[0]) + ", o)) * rcp_fast(dot(" + v3(g[0]) + ", d)); f3 p = madd(d, t, o);\n";
+                s += "      float x = fmaf(" + lit(g1.z) + ", p.z, fmaf(" + lit(g1.y) + ", p.y, fmaf(" + lit(g1.x) + ", p.x, " + lit(g1.w) + ")));\n";
+                s += "      float y = fmaf(" + lit(g2.z) + ", p.z, fmaf(" + lit(g2.y) + ", p.y, fmaf(" + lit(g2.x) + ", p.x, " + lit(g2.w) + ")));\n";
+                if (run.x == PRIM_RECT) s += "      bool in = (fabsf(x) <= " + lit(g3.x) + ") & (fabsf(y) <= " + lit(g3.y) + ");\n";
+                else                    s += "      bool in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);\n";
+                s += "      bool hit = (t >= tminp) & (t <= closest) & in; " + take;
+            }
+            q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
+        }
+    }
+    s += "    t_out = closest;\n    return best;\n}\n} // namespace rt\n";
+    return s;
+}
+
+uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ULL;
+    for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ULL; }
+    return h;
+}
+
+struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::string note; };
+std::mutex g_mu;
+std::map<std::pair<int, uint64_t>, Entry> g_cache;   // (device, source hash)
+
+}  // namespace
+
+hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, std::string& note) {
+    size_t n_prims = 0;
+    for (const int4& r : sruns) n_prims += (size_t)r.z;
+    if (n_prims == 0 || n_prims > RT_JIT_MAX_PRIMS) { note = "scene has " + std::to_string(n_prims) + " slots (specialised up to " + std::to_string(RT_JIT_MAX_PRIMS) + ")"; return nullptr; }
+    std::string src = std::string("#define RT_JIT_SCENE 1\ntypedef unsigned int uint32_t; typedef unsigned char uint8_t; typedef unsigned long long uint64_t; typedef unsigned long uintptr_t;\n") + kSrcArgs + "\n" + kSrcDevice + "\n" + gen_closest_hit(slots, sruns) + kSrcPath +
+        "\nextern \"C\" __global__ __launch_bounds__(256) void k_path_jit(rt::DevScene SD, rt::PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
+        "    rt::path_body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
+    int dev = 0; (void)hipGetDevice(&dev);
+    const auto key = std::make_pair(dev, fnv1a(src));
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) { note = it->second.note; return it->second.fn; }
+    Entry e;
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "rt_path_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) e.note = "hiprtcCreateProgram failed";
+    else {
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize"};
+        hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+        if (r != HIPRTC_SUCCESS) {
+            size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
+            std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
+            e.note = "hiprtc compile failed: " + log.substr(0, 2000);
+        } else {
+            size_t n = 0; hiprtcGetCodeSize(prog, &n);
+            std::vector<char> code(n); hiprtcGetCode(prog, code.data());
+            if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, "k_path_jit") != hipSuccess) { e.fn = nullptr; e.note = "hipModuleLoadData/GetFunction failed"; }
+        }
+        hiprtcDestroyProgram(&prog);
+    }
+    g_cache[key] = e;
+    note = e.note;
+    return e.fn;
+}
+
+} // namespace rt

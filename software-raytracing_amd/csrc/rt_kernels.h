@@ -4,39 +4,13 @@
 #include <stdint.h>
 #include "../../include/rt_mi355.h"
 
-#define RT_LDS_SCENE_MAX_BYTES (48 * 1024)
+#include "rt_args.h"
 
 namespace rt {
 struct DevScene;
 
-// Ray counters: one 64-bit atomic per wave and counter; 130k waves hitting ONE address cost ~3 ms at 4K (the whole 01
-// frame takes less), so the atomics are spread over banks (bank = block index mod RT_COUNTER_BANKS), summed on the host.
-#define RT_COUNTER_BANKS 256
-#define RT_COUNTER_WORDS (2 * RT_COUNTER_BANKS)
-
-struct PathArgs {
-    int width, height;
-    int sample_begin, sample_end;   // samples [begin,end) of every pixel
-    int slice_len;                  // samples per blockIdx.y slice
-    int max_depth;
-    int jitter;                     // spp > 1 (03 Main.cpp:331)
-    int regen_threshold;            // idle lanes per wave that trigger a regeneration pass
-    int debug_flags;                // bit 1 (2): no LDS staging (A/B switch); bit 2 (4): accumulator w = rays of the pixel
-    uint32_t seed;
-    float t_min, t_min_pos, t_max;  // t_min_pos = max(t_min, smallest positive float): "t > 0 && t >= tMin" in one compare
-    float inv_w2, inv_h2, kx, ky;   // 2/w, 2/h, tan(fov/2)*w/h, tan(fov/2)
-    float r[9];                     // GetRotationMat(orientation), row-major
-    float px, py, pz;
-};
-
-struct WhittedArgs {
-    int width, height, max_depth, shadow_samples;
-    uint32_t seed;
-    float w, h, tan_half;           // float(width), float(height), tanf(fovRadians/2) (01 Main.cpp:329-341)
-    int stack_bytes, shadow_lds;    // set by launch_whitted: LDS bytes of the recursion stack; slot layout staged behind it for 02's shadow samples
-};
-
-void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st);
+// jit: scene-specialised kernel for this scene (rt_jit.h) or nullptr
+void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit);
 void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* out, hipStream_t st);
 void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st);
 void launch_resolve(const float4* accum, int width, int height, float divisor, int gamma, uint8_t* bgra, int stride, float* rgb, hipStream_t st);

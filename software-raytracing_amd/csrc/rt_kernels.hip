@@ -3,257 +3,39 @@
 #include "rt_device.h"
 #include "rt_strict.h"
 #include "rt_kernels.h"
+#include "rt_path_device.h"
 
 namespace rt {
 
 // =================================================================================================
-// K3/K4: path tracing.  Render + TraceTay of 03 (Main.cpp:310-435) and 04 (Main.cpp:324-502).
-// The recursion out = att * child (+ emitted) is a product chain, so it runs as a loop carrying
-// the throughput; a lane whose path ended takes the next sample of its pixel (regeneration),
-// and a wave regenerates only when enough of its lanes are idle (ballot), so lanes stay busy
-// without paying the camera code on every iteration.
+// K3/K4: path tracing (device code in rt_path_device.h).
 // =================================================================================================
-// Per-lane path state of the bounce loop.
-struct PathLane {
-    f3 o, d, thr, acc;
-    uint32_t skey;
-    int depth, s_next, n_started;
-    unsigned int rays;
-    bool alive;
-};
-__device__ __forceinline__ PathLane lane_init(int s_next) {
-    PathLane L;
-    L.o = F3(0, 0, 0); L.d = F3(0, 0, -1); L.thr = F3(0, 0, 0); L.acc = F3(0, 0, 0);
-    L.skey = 0; L.depth = 0; L.s_next = s_next; L.n_started = 0; L.rays = 0; L.alive = false;
-    return L;
-}
-
-// Path regeneration: idle lanes ('want') take the next sample of their pixel once enough of the wave is idle.
-__device__ __forceinline__ void regenerate(const PathArgs& A, int px, int py, uint32_t pkey, bool want, unsigned long long m_want, unsigned long long m_alive, PathLane& L) {
-    if (m_want && (m_alive == 0ULL || __popcll(m_want) >= A.regen_threshold)) {
-        if (want) {   // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369)
-            L.skey = rng_sample_key(pkey, (uint32_t)L.s_next);
-            float bx = 0.5f, by = 0.5f;
-            if (A.jitter) rng_pair(L.skey, 0U, bx, by);
-            float x = fmaf((float)px + bx, A.inv_w2, -1.0f) * A.kx;
-            float y = -fmaf((float)py + by, A.inv_h2, -1.0f) * A.ky;
-            f3 v = F3(x, y, -1.0f);
-            L.d = normalize(F3(dot(F3(A.r[0], A.r[1], A.r[2]), v), dot(F3(A.r[3], A.r[4], A.r[5]), v), dot(F3(A.r[6], A.r[7], A.r[8]), v)));
-            L.o = F3(A.px, A.py, A.pz);
-            L.thr = F3(1, 1, 1);
-            L.depth = 0;
-            L.alive = true;
-            ++L.s_next; ++L.n_started;
-        }
-    }
-}
-// wave-level state of the bounce loop: which lanes are idle with samples left, which are tracing
-#define RT_WAVE_STATE(L, s_end) \
-    const bool want = !(L).alive && (L).s_next < (s_end); \
-    const unsigned long long m_want = __builtin_amdgcn_ballot_w64(want), m_alive = __builtin_amdgcn_ballot_w64((L).alive)
-
-// One bounce after the scene query: miss / emit / scatter (TraceTay of 03 Main.cpp:392-435, 04 Main.cpp:447-502).
-// hit = SceneMem address of the winning slot (0 = miss), t = its distance.
-template <int VARIANT, bool LDS>
-__device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, uint32_t mats0, uint32_t hit, float t, PathLane& L) {
-    if (hit == 0U) {
-        if (VARIANT == 3) {   // sky: Mix(white, (0.5,0.7,1), 0.5*(d.y+1)) (03 Main.cpp:430-432)
-            float h = 0.5f * (L.d.y + 1.0f);
-            L.acc = L.acc + L.thr * F3(fmaf(-0.5f, h, 1.0f), fmaf(-0.3f, h, 1.0f), 1.0f);
-        }
-        L.alive = false;
-    } else {
-        // hit record (03 Sphere.hpp:57-73; 04 Scene/Sphere.hpp:58-74, Plane.hpp:55-66, Rectangle.hpp:79-92), one
-        // formula for every primitive type (slot layout, rt_device.h): n = (p - c)*k + m, turned against the ray
-        float4 sa = M.ld4(hit + SLOT_A), sb = M.ld4(hit + SLOT_B), sc = M.ld4(hit + SLOT_C);
-        L.o = madd(L.d, t, L.o);                       // the hit point is the next origin; nothing below needs the old one
-        f3 pc = L.o - F3(sa);
-        // spheres: Normalize(p - c) (k = +-1; also right when the hit was reported at tMax, off the surface); others: k = 0
-        float k = sa.w * rsq_fast(fmaf(pc.z, pc.z, fmaf(pc.y, pc.y, fmaf(pc.x, pc.x, 1e-30f))));
-        f3 n = madd(pc, k, F3(sb));
-        float facing = dot(L.d, madd(pc, k, F3(sc)));
-        bool back = facing > 0.0f;
-        // n = back ? -n : n through the sign bit of (0 - facing): set exactly when facing > 0
-        uint32_t flip = __float_as_uint(0.0f - facing) & 0x80000000U;
-        n = F3(__uint_as_float(__float_as_uint(n.x) ^ flip), __uint_as_float(__float_as_uint(n.y) ^ flip), __uint_as_float(__float_as_uint(n.z) ^ flip));
-        const uint32_t moff = mats0 + __float_as_uint(sb.w);
-        float4 m0 = M.ld4(moff), m2 = M.ld4(moff + 32U);
-        int mtype = __float_as_int(m0.w);
-        if (mtype == MAT_DIFFUSE || mtype == MAT_METAL || mtype == MAT_DIELECTRIC) {
-            // one draw per bounce serves whichever material was hit: (fi, theta) halves for the hemisphere/cone
-            // samplers, the top 24 bits for the dielectric's reflect-or-refract choice
-            const uint32_t r = rng_bits(L.skey, 4U * ((uint32_t)L.depth + 1U));
-            const float dn = dot(L.d, n);
-            const f3 refl = madd(n, -2.0f * dn, L.d);          // math::Reflect (Math.hpp:291-294)
-            f3 nd;
-            if (mtype == MAT_DIELECTRIC) {                   // 03 Materials.hpp:233-265, 04 Refractive.hpp:80-104
-                float eta = back ? m0.x : m2.z;              // m0.x = 1/refractionIndex (host-precomputed)
-                float q = 1.0f - fmaxf(-dn, 0.0f), q2 = q * q;
-                float refl_p = fmaf(1.0f - m2.w, q2 * q2 * q, m2.w);
-                float u = (float)(r >> 8) * (1.0f / 16777216.0f);
-                // math::Refract, reflect-on-TIR form (Math.hpp:306-312)
-                float k = fmaf(-eta * eta, fmaf(-dn, dn, 1.0f), 1.0f);
-                float s = fmaf(eta, dn, sqrt_fast(fmaxf(k, 0.0f)));
-                f3 refr = madd(n, -s, L.d * eta);
-                nd = sel((refl_p < u) & !(k < 0.0f), refr, refl);
-            } else {
-                f3 axis = sel(mtype == MAT_METAL, refl, n);
-                nd = axis;
-                if (m2.y >= 0.0f) {
-                    // RndHemisphereVec (03 Utils.h:64-88) / RndHemisphereVec3 (04 Utils.h:132-157)
-                    float u_fi = (float)(r & 0xFFFFU) * (1.0f / 65536.0f), u_th = (float)(r >> 16) * (1.0f / 65536.0f);
-                    // b = Normalize(Cross(dir, dir + 0.01)) = Normalize(Cross(dir, (1,1,1))): the 0.01 and dir x dir cancel;
-                    // c = Cross(dir, b) is already unit (dir, b orthonormal), so the reference's second Normalize is a no-op
-                    f3 b = F3(axis.y - axis.z, axis.z - axis.x, axis.x - axis.y);
-                    float bl2 = dot(b, b);
-                    bool degenerate = !(bl2 > 0.0f);
-                    b = b * (degenerate ? 0.0f : rsq_fast(bl2));      // Normalize(0) = 0: the frame collapses for dir parallel to (1,1,1)
-                    f3 c = cross(axis, b);
-                    // fi = U*360/57.2958; cos from the hardware (input in revolutions), sin = +-sqrt(1 - cos^2) so that
-                    // cos^2 + sin^2 = 1 to the last bit: v_sin/v_cos are each good to ~1e-5 only, and the sphere test
-                    // amplifies an error in |L.d| by (distance/radius)^2
-                    const float fi_rev = (float)((360.0 / 57.2958f) / 6.283185307179586);   // fi/(2*pi)
-                    float x_rev = u_fi * fi_rev;
-                    float cf = __builtin_amdgcn_cosf(x_rev);
-                    float sf = sqrt_fast(fmaf(-cf, cf, 1.0f));
-                    sf = __uint_as_float(__float_as_uint(sf) | (__float_as_uint(0.5f - x_rev) & 0x80000000U));   // negative beyond half a turn
-                    float ct, st;
-                    if (VARIANT == 3) {   // theta = U(-1,1)*thetaMax/57.2958
-                        float th_rev = (2.0f * u_th - 1.0f) * m2.y * 0.15915494309189535f;
-                        ct = __builtin_amdgcn_cosf(th_rev);
-                        st = sqrt_fast(fmaf(-ct, ct, 1.0f));
-                        st = __uint_as_float(__float_as_uint(st) | (__float_as_uint(th_rev) & 0x80000000U));      // |theta| <= 90 deg: sin has theta's sign
-                    } else {              // theta = acos(U(cos(thetaMax/57.2958), 1))
-                        ct = fmaf(1.0f - m2.y, u_th, m2.y);
-                        st = sqrt_fast(fmaf(-ct, ct, 1.0f));   // ct <= 1 exactly (u_th < 1), so the fused 1 - ct*ct is never negative
-                    }
-                    nd = madd(madd(c, sf, b * cf), st, axis * ct);
-                    // Ray's constructor normalises (Common/Ray.hpp:33-34); nd is unit by construction unless the frame
-                    // collapsed, where it is axis*cos(theta)
-                    if (degenerate) nd = normalize(nd);
-                }
-            }
-            L.d = nd;   // unit: n is unit (slot layout), Reflect/Refract keep the length, the sampled direction is unit by construction
-            if (mtype != MAT_DIELECTRIC) {
-                f3 att = F3(m0);
-                if (VARIANT == 4) att = att * fmaxf(dot(L.d, n), 0.0f);      // 04 Diffuse.hpp:77-78, Metal.hpp:83-84
-                L.thr = L.thr * att;
-            }
-            ++L.depth;
-        } else {
-            if (VARIANT == 4 && mtype == MAT_LIGHT && !back) L.acc = L.acc + L.thr * F3(m0);   // Light.hpp:47-54, Main.cpp:480-483
-            L.alive = false;
-        }
-        if (L.depth > A.max_depth) L.alive = false;   // 03 Main.cpp:383-386, 04 Main.cpp:438-441
-    }
-}
-
-// Small scenes (blob <= 48 KB, LDS = true): every block stages the whole blob in LDS once.  LDS = false: the blob is
-// read from global memory with scalar loads (debug flag 2; A/B reference for the other two kernels).
 template <int VARIANT, bool LDS>
 __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
-    extern __shared__ float4 smem[];
-    const char* base = reinterpret_cast<const char*>(SD.blob);
-    if (LDS) {   // primitive operands then arrive in VGPRs (ds_read), not SGPRs
-        for (int i = threadIdx.x; i < SD.total_f4; i += 256) smem[i] = SD.blob[i];
-        __syncthreads();
-        base = reinterpret_cast<const char*>(smem);
-    }
-    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);   // always global: scalar loads
-    const SceneMem<LDS> M{base};
-    const uint32_t slots0 = M.at((uint32_t)SD.off_slots * 16U), mats0 = M.at(0U);
-    int px, py;
-    bool inside = pixel_of_thread(A.width, A.height, px, py);
-    const int slice = blockIdx.y;
-    int s_first = A.sample_begin + slice * A.slice_len;
-    const int s_end = min(s_first + A.slice_len, A.sample_end);
-    if (!inside) s_first = s_end;
-    const uint32_t pixel = (uint32_t)(py * A.width + px);
-    const uint32_t pkey = rng_pixel_key(A.seed, pixel);
-    PathLane L = lane_init(s_first);
-
-    for (;;) {
-        RT_WAVE_STATE(L, s_end);
-        if ((m_want | m_alive) == 0ULL) break;
-        regenerate(A, px, py, pkey, want, m_want, m_alive, L);
-        if (L.alive) {
-            // TraceTay: one scene query (03 Main.cpp:392, 04 Main.cpp:447)
-            ++L.rays;
-            float t;
-            uint32_t hit = closest_hit_slots<LDS>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
-            shade<VARIANT, LDS>(M, A, mats0, hit, t, L);
-        }
-    }
-    if (inside) {
-        // debug flag 4: report the lane's scene-query count in w instead of its sample count (parity diagnostics)
-        out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);
-    }
-    wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
+    path_body<VARIANT, LDS>(SD, A, out, counters);
 }
-
-// Large scenes (blob > 48 KB): the slot section is walked in pieces of <= RT_TILE_BYTES that the block's four waves
-// stage through LDS together (one global read per block instead of one per wave, and VGPR operands for the tests), so
-// the bounce loop runs in lockstep per BLOCK: regenerate per wave, then every chunk between two barriers, then shade.
-// The winner is remembered as a blob offset (its chunk is gone from LDS by shading time) and shaded from global memory.
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_path_tiled(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
-    extern __shared__ float4 smem[];
-    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
-    const int4* __restrict__ chunks = reinterpret_cast<const int4*>(SD.blob + SD.off_chunks);
-    const SceneMem<false> G{reinterpret_cast<const char*>(SD.blob)};
-    const SceneMem<true> T{reinterpret_cast<const char*>(smem)};
-    const uint32_t tile0 = T.at(0U);
-    int px, py;
-    bool inside = pixel_of_thread(A.width, A.height, px, py);
-    const int slice = blockIdx.y;
-    int s_first = A.sample_begin + slice * A.slice_len;
-    const int s_end = min(s_first + A.slice_len, A.sample_end);
-    if (!inside) s_first = s_end;
-    const uint32_t pixel = (uint32_t)(py * A.width + px);
-    const uint32_t pkey = rng_pixel_key(A.seed, pixel);
-    PathLane L = lane_init(s_first);
-
-    for (;;) {
-        {
-            RT_WAVE_STATE(L, s_end);
-            regenerate(A, px, py, pkey, want, m_want, m_alive, L);
-        }
-        if (!__syncthreads_or(L.alive)) break;      // block-uniform: a finished wave keeps staging chunks for the others
-        float closest = A.t_max;
-        uint32_t best = 0U;
-        const f3 inv_d = F3(rcp_fast(L.d.x), rcp_fast(L.d.y), rcp_fast(L.d.z));
-        for (int c = 0; c < SD.n_chunks; ++c) {
-            const int4 ch = chunks[c];
-            const float4* __restrict__ src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(SD.blob) + ch.x);
-            if (c) __syncthreads();                 // everyone is done with the previous chunk
-            for (int i = threadIdx.x; i < (ch.y >> 4); i += 256) smem[i] = src[i];
-            __syncthreads();
-            if (L.alive) {
-                uint32_t b = 0U;
-                closest_hit_runs<true>(T, runs + ch.z, ch.w, tile0, L.o, L.d, inv_d, A.t_min, A.t_min_pos, closest, b);
-                if (b) best = b - tile0 + (uint32_t)ch.x;
-            }
-        }
-        if (L.alive) {
-            ++L.rays;
-            shade<VARIANT, false>(G, A, 0U, best, closest, L);
-        }
-    }
-    if (inside) out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);
-    wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
+    path_tiled_body<VARIANT>(SD, A, out, counters);
 }
 
 template <int VARIANT>
-static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st) {
+static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 15) / 16), n_slices);
     size_t bytes = (size_t)S.total_f4 * sizeof(float4);
+    if (jit && bytes <= RT_LDS_SCENE_MAX_BYTES) {   // scene-specialised k_path<VARIANT, true> (rt_jit.hip)
+        DevScene s = S; PathArgs a = A;
+        void* params[] = {&s, &a, &out, &counters};
+        (void)hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)bytes, st, params, nullptr);
+        return;
+    }
     if (A.debug_flags & 2)                   hipLaunchKernelGGL((k_path<VARIANT, false>), grid, dim3(256), 0, st, S, A, out, counters);   // A/B reference: scalar loads from the global blob
     else if (bytes <= RT_LDS_SCENE_MAX_BYTES) hipLaunchKernelGGL((k_path<VARIANT, true>), grid, dim3(256), bytes, st, S, A, out, counters);  // small scene: LDS-resident
     else                                     hipLaunchKernelGGL((k_path_tiled<VARIANT>), grid, dim3(256), RT_TILE_BYTES, st, S, A, out, counters);   // large scene: LDS-tiled
 }
-void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st) {
-    if (variant == 3) launch_path_v<3>(S, A, out, n_slices, counters, st);
-    else              launch_path_v<4>(S, A, out, n_slices, counters, st);
+void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
+    if (variant == 3) launch_path_v<3>(S, A, out, n_slices, counters, st, jit);
+    else              launch_path_v<4>(S, A, out, n_slices, counters, st, jit);
 }
 
 // Sum the per-slice partial images in a fixed order (deterministic), out = float4(sum rgb, samples).

@@ -45,6 +45,7 @@ def load():
         L.rt_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_debug_set_regen_threshold.argtypes = [C.c_void_p, C.c_int32]
         L.rt_debug_set_flags.argtypes = [C.c_void_p, C.c_int32]
+        L.rt_debug_last_path_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
         _LIB = L
     return _LIB
 
@@ -115,6 +116,12 @@ class Context:
 
     def set_regen_threshold(self, n):
         self._chk(self.L.rt_debug_set_regen_threshold(self.h, n))
+
+    def last_path_kernel(self):
+        """(kind, note): 2 scene-specialised (hiprtc), 1 generic LDS-resident, 0 tiled / global; note = why not specialised"""
+        buf = C.create_string_buffer(2048)
+        kind = self.L.rt_debug_last_path_kernel(self.h, buf, 2048)
+        return kind, buf.value.decode(errors="replace")
 
     def set_debug_flags(self, f):
         self._chk(self.L.rt_debug_set_flags(self.h, f))

@@ -207,6 +207,34 @@ def test_stress_scene_reduced_tiled_kernel(ctx):
         assert abs(g["rays"] - o["rays"]) <= max(2, 2e-2 * o["rays"]) and g["samples"] == w * h * 4
 
 
+@pytest.mark.parametrize("which", ["04", "03", "mixed"])
+def test_scene_specialised_kernel_matches_generic(ctx, which):
+    """Small scenes run a kernel whose scene query was generated for that scene (hiprtc, rt_jit.hip): same arithmetic
+    operation for operation as the generic loops, so the images must be identical, not merely close."""
+    if which == "04":
+        s, cam, prm = scenes.scene04(8, seed=5)
+    elif which == "03":
+        s, cam, prm = scenes.scene03(8, seed=5, readme_variant=True)
+    else:
+        s = scenes.Scene()
+        white = s.diffuse((0.7, 0.7, 0.7)); metal = s.metal((0.9, 0.8, 0.7), 0.1); glass = s.dielectric(0.7); lm = s.light_material((8, 7, 6))
+        s.plane(white, (0, -3, 0), (0, 1, 0)); s.plane(white, (0, 0, -12), (0.2, 0.1, 1.0))
+        s.triangle(metal, (-6, -3, -9), (-1, -3, -11), (-4, 3, -10)); s.box(white, (3, -2, -7), (2, 2, 2), (0, 30, 10))
+        s.sphere(glass, (0, -1.5, -6), 1.5); s.sphere(-1, (3, 0.5, -7), 0.5)
+        s.rect(lm, (0, 5, -6), (4, 3), (70, 20, 0))
+        cam = scenes.camera(75.0, (0.5, 0.2, 2.0), (-5, 8, 3)); prm = scenes.path_params(abi.RT_PATH_LIGHTS, 8, max_depth=5, seed=4)
+    a = ctx.render_path(s, cam, prm, 128, 96)
+    kind, note = ctx.last_path_kernel()
+    assert kind == 2, f"scene-specialised kernel not used: {note}"
+    ctx.set_debug_flags(8)
+    try:
+        b = ctx.render_path(s, cam, prm, 128, 96)
+        assert ctx.last_path_kernel()[0] == 1
+    finally:
+        ctx.set_debug_flags(0)
+    assert a["rays"] == b["rays"] and np.array_equal(a["rgb"], b["rgb"])
+
+
 def test_lds_and_global_scene_paths_agree(ctx):
     """The same small scene through the LDS-staged kernel and (debug flag) the global-memory kernel: identical images."""
     s, cam, prm = scenes.scene04(8, seed=5)

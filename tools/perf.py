@@ -14,4 +14,4 @@ for name, (s, cam, prm), (w, h), fpr in [("04", scenes.scene04(256), (3840, 2160
             g = ctx.render_path(s, cam, prm, w, h)
             best = g if best is None or g["kernel_ms"] < best["kernel_ms"] else best
         r = best["rays"] / best["kernel_ms"] / 1e6
-        print(f"{name} {w}x{h} spp {prm.spp} flags {t}: {best['kernel_ms']:.2f} ms  {r:.2f} Grays/s  {r*fpr/1e3/157.3*100:.1f}% of FP32 peak  ({best['rays']/best['samples']:.3f} rays/sample)", flush=True)
+        print(f"{name} {w}x{h} spp {prm.spp} flags {t} kernel {ctx.last_path_kernel()[0]}: {best['kernel_ms']:.2f} ms  {r:.2f} Grays/s  {r*fpr/1e3/157.3*100:.1f}% of FP32 peak  ({best['rays']/best['samples']:.3f} rays/sample)", flush=True)
