@@ -12,6 +12,7 @@
 #include <hip/hiprtc.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -114,6 +115,10 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
         } else {
             size_t n = 0; hiprtcGetCodeSize(prog, &n);
             std::vector<char> code(n); hiprtcGetCode(prog, code.data());
+            if (const char* dump = getenv("RT_MI355_JIT_DUMP")) {   // <prefix>.hip = generated source, <prefix>.co = code object (llvm-objdump -d)
+                if (FILE* f = fopen((std::string(dump) + ".hip").c_str(), "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
+                if (FILE* f = fopen((std::string(dump) + ".co").c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+            }
             if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, "k_path_jit") != hipSuccess) { e.fn = nullptr; e.note = "hipModuleLoadData/GetFunction failed"; }
         }
         hiprtcDestroyProgram(&prog);

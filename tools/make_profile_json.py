@@ -16,7 +16,7 @@ for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
     agg = collections.defaultdict(float); launches = set()
     for f in glob.glob(os.path.join(src, name, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if "k_path" in r["Kernel_Name"]:
+            if "k_path" in r["Kernel_Name"] and int(r["Grid_Size"]) > 1000000:   # the bench frame, not the 16x16 setup render
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); launches.add(r["Dispatch_Id"])
     passes[name] = dict(agg); passes[name + "_launches"] = len(launches)
 b = json.loads(line(os.path.join(src, "pmc_sq.json")))
@@ -26,7 +26,7 @@ n = max(1, passes["pmc_sq_launches"])
 valu = sq["SQ_INSTS_VALU"] / n
 d = {
     "command": "rocprofv3 --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (one run per counter group, tools/collect_profiles.sh)",
-    "kernel": "rt::k_path<4, true>", "workload": "x".join(re.search(r"(\d+)x(\d+), (\d+) spp", b["config"]["workload"]).groups()), "launches_per_pass": n, "passes": {k: v for k, v in passes.items() if not k.endswith("_launches")},
+    "kernel": b["roofline"]["kernel"], "workload": "x".join(re.search(r"(\d+)x(\d+), (\d+) spp", b["config"]["workload"]).groups()), "launches_per_pass": n, "passes": {k: v for k, v in passes.items() if not k.endswith("_launches")},
     "derived": {
         "valu_wave_instructions": valu, "salu_wave_instructions": sq["SQ_INSTS_SALU"] / n,
         "valu_lane_utilisation": sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_ACTIVE_INST_VALU"] * 64) if sq.get("SQ_ACTIVE_INST_VALU") else None,
