@@ -434,7 +434,7 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     A.debug_flags = c->debug_flags;
     // camera code costs about as much as testing 20 primitives: with few primitives wait for a batch of idle lanes,
     // with many refill every idle lane at once (measured: tools/sweep_regen.py, tools/sweep_regen_stress.py)
-    A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : (scene->n_prims >= 128 ? 1 : (p->variant == RT_PATH_LIGHTS ? 16 : 8));
+    A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : (scene->n_prims >= 128 ? 1 : 16);
     float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 03 Main.cpp:317
     float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
     A.inv_w2 = 2.0f / w; A.inv_h2 = 2.0f / h; A.kx = th * w / h; A.ky = th;
