@@ -101,9 +101,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one-time setup, like loading the library: the first render of a scene compiles its specialised kernel (hiprtc, ~1 s)
-    # (only needed when there is no warmup step to absorb it)
-    if args.warmup == 0:
+    # one-time setup, like loading the library: the library compiles a kernel specialised for a scene (hiprtc, ~0.7 s) when it
+    # sees the scene for the second time; two tiny renders put that before the warmup/timed steps whatever --warmup is
+    for _ in range(2):
         ctx.render_path(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, 1, seed=1), 16, 16)
     for _ in range(args.warmup):
         step()

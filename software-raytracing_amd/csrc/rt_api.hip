@@ -449,10 +449,12 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     if (slices > 1) { HIPCHK(c, c->partial.reserve(npx * slices * sizeof(float4))); target = (float4*)c->partial.p; }
     if ((rc = begin_timed(c, st))) return rc;
     // small scenes: the scene query compiled for THIS scene (literal operands, no loops); debug flag 8 or RT_MI355_JIT=0 keeps
-    // the generic kernel (A/B and parity tests); an unavailable hiprtc is not an error, the generic kernel renders the same image
+    // the generic kernel, debug flag 16 or RT_MI355_JIT=2 specialises at the first render (A/B and parity tests); an unavailable hiprtc is not an error, the generic kernel renders the same image
     hipFunction_t jit = nullptr;
     const char* jit_env = getenv("RT_MI355_JIT");
-    if (!(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES)
+    c->jit_note.clear();
+    if (!(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
+        jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
         jit = jit_path_kernel(p->variant, H.slots, H.sruns, c->jit_note);
     c->last_path_kernel = jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0);
     launch_path(p->variant, D, A, target, slices, c->d_counters, st, jit);

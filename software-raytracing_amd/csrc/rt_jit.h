@@ -7,5 +7,7 @@
 namespace rt {
 // Returns the kernel for this (variant, slot section) or nullptr when specialisation is unavailable (hiprtc missing, compile
 // error, scene too large); 'note' then says why.  Compiled kernels are cached per process by the hash of their source.
+// Policy: whether this render should use (and, if need be, compile) the specialised kernel; counts sightings of the scene.
+bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, double job_samples, bool force, std::string& note);
 hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, std::string& note);
 }

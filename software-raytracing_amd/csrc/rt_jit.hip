@@ -90,6 +90,25 @@ std::map<std::pair<int, uint64_t>, Entry> g_cache;   // (device, source hash)
 
 }  // namespace
 
+// When to pay the ~0.7 s compile: a scene that is rendered once at example size would lose by it, a scene that is rendered
+// again (progressive / interactive use, benchmarks) or for seconds wins.  So: compile on the SECOND render of the same
+// scene in this process, or at once when the job is large or the caller forces it; never for more than RT_JIT_MAX_SCENES
+// distinct scenes per process (an animation would compile every frame).
+constexpr size_t RT_JIT_MAX_SCENES = 64;
+constexpr double RT_JIT_BIG_JOB_SAMPLES = 5e10;
+std::map<uint64_t, int> g_sightings;
+
+bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, double job_samples, bool force, std::string& note) {
+    uint64_t h = 1469598103934665603ULL ^ (uint64_t)variant;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ULL; } };
+    mix(slots.data(), slots.size() * sizeof(float4)); mix(sruns.data(), sruns.size() * sizeof(int4));
+    std::lock_guard<std::mutex> lock(g_mu);
+    int seen = g_sightings.size() < 4096 || g_sightings.count(h) ? ++g_sightings[h] : 1;
+    if (force || seen >= 2 || job_samples >= RT_JIT_BIG_JOB_SAMPLES) return true;
+    note = "first render of this scene and a small job: generic kernel (specialised from the second render on)";
+    return false;
+}
+
 hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, std::string& note) {
     size_t n_prims = 0;
     for (const int4& r : sruns) n_prims += (size_t)r.z;
@@ -102,6 +121,7 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { note = it->second.note; return it->second.fn; }
+    if (g_cache.size() >= RT_JIT_MAX_SCENES) { note = "more than " + std::to_string(RT_JIT_MAX_SCENES) + " distinct scenes in this process: generic kernel"; return nullptr; }
     Entry e;
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rt_path_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) e.note = "hiprtcCreateProgram failed";

@@ -223,7 +223,11 @@ def test_scene_specialised_kernel_matches_generic(ctx, which):
         s.sphere(glass, (0, -1.5, -6), 1.5); s.sphere(-1, (3, 0.5, -7), 0.5)
         s.rect(lm, (0, 5, -6), (4, 3), (70, 20, 0))
         cam = scenes.camera(75.0, (0.5, 0.2, 2.0), (-5, 8, 3)); prm = scenes.path_params(abi.RT_PATH_LIGHTS, 8, max_depth=5, seed=4)
-    a = ctx.render_path(s, cam, prm, 128, 96)
+    ctx.set_debug_flags(16)          # specialise at the first render (the default waits for the second render of a scene)
+    try:
+        a = ctx.render_path(s, cam, prm, 128, 96)
+    finally:
+        ctx.set_debug_flags(0)
     kind, note = ctx.last_path_kernel()
     assert kind == 2, f"scene-specialised kernel not used: {note}"
     ctx.set_debug_flags(8)
@@ -233,6 +237,9 @@ def test_scene_specialised_kernel_matches_generic(ctx, which):
     finally:
         ctx.set_debug_flags(0)
     assert a["rays"] == b["rays"] and np.array_equal(a["rgb"], b["rgb"])
+    # default policy: a scene is specialised from its second render on (this one has been seen twice already)
+    c = ctx.render_path(s, cam, prm, 128, 96)
+    assert ctx.last_path_kernel()[0] == 2 and np.array_equal(a["rgb"], c["rgb"])
 
 
 def test_lds_and_global_scene_paths_agree(ctx):
