@@ -101,9 +101,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one-time setup, like loading the library: the library compiles a kernel specialised for a scene (hiprtc, ~0.7 s) when it
-    # sees the scene for the second time; two tiny renders put that before the warmup/timed steps whatever --warmup is
-    for _ in range(2):
+    # one-time setup, like loading the library: the library compiles a kernel specialised for this scene (hiprtc, ~0.7 s).  Its
+    # default is to do that when it sees a scene for the second time; here it is asked to do it at the first render, which
+    # is the first warmup step (with --warmup 0: a tiny 16x16 render, so that the compile is never inside the timed region)
+    ctx.set_debug_flags(16)
+    if args.warmup == 0:
         ctx.render_path(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, 1, seed=1), 16, 16)
     for _ in range(args.warmup):
         step()
