@@ -1,6 +1,7 @@
 // 04 - Path tracing with lights, headless: scene literals of Sources/04_PathTracingLights/Main.cpp:181-199,
 // Render(&fb, scene, 90, SAMPLES_PER_PIXEL = 32, {0,0,10}, {0,0,0}) :203.
 #include "../host/04_PathTracingLights/Render.hpp"
+#include "../host/Common/Progressive.hpp"
 #include "headless.hpp"
 
 #define SAMPLES_PER_PIXEL 32
@@ -34,6 +35,21 @@ int main(int argc, char* argv[]) {
         if (!opt.dump.empty()) { rtbackend::Flat flat; path_detail::flatten(scene.getElements(), &flat); DumpFlat(flat, opt.dump); return 0; }
 
         auto renderBeginTime = std::chrono::system_clock::now();
+        if (opt.chunk) {
+            // progressive: --chunk samples per pass, the running sums kept in --checkpoint so that an interrupted run
+            // (--stop-after N simulates one) continues where it stopped; the finished frame equals the one-shot frame
+            rtbackend::Flat flat; path_detail::flatten(scene.getElements(), &flat);
+            const rt_scene sc = flat.scene();
+            const rt_camera cam{90.0f, {0.0f, 0.0f, 10.0f}, {0.0f, 0.0f, 0.0f}};
+            ProgressiveFrame frame(opt.width, opt.height, opt.samples, RenderSeed(), 4);
+            if (!opt.checkpoint.empty() && frame.load(opt.checkpoint)) std::cout << "INFO: Resumed at sample " << frame.samplesDone() << std::endl;
+            while (!frame.complete() && !(opt.stopAfter && frame.samplesDone() >= opt.stopAfter)) {
+                frame.accumulate(sc, cam, opt.chunk);
+                if (!opt.checkpoint.empty()) frame.save(opt.checkpoint);
+            }
+            std::cout << "INFO: " << frame.samplesDone() << " of " << opt.samples << " samples per pixel done" << std::endl;
+            frame.resolve(&frameBuffer);
+        } else
         Render(&frameBuffer, scene, 90.0f, opt.samples, {0.0f, 0.0f, 10.0f}, {0.0f, 0.0f, 0.0f});
         std::cout << "INFO: Scene rendered in " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - renderBeginTime).count() << " ms." << std::endl;
         PrintBackendStats();

@@ -11,7 +11,8 @@
 
 struct Options {
     unsigned width = 784, height = 561, samples = 0, seed = 1;
-    std::string out, dump;
+    std::string out, dump, checkpoint;
+    unsigned chunk = 0, stopAfter = 0;   // progressive rendering: samples per pass, stop early (to be resumed)
 };
 
 inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
@@ -29,7 +30,10 @@ inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
         else if (const char* v = value("--seed")) o.seed = static_cast<unsigned>(std::strtoul(v, nullptr, 10));
         else if (const char* v = value("--out")) o.out = v;
         else if (const char* v = value("--dump-scene")) o.dump = v;
-        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene)");
+        else if (const char* v = value("--checkpoint")) o.checkpoint = v;
+        else if (const char* v = value("--chunk")) o.chunk = static_cast<unsigned>(std::atoi(v));
+        else if (const char* v = value("--stop-after")) o.stopAfter = static_cast<unsigned>(std::atoi(v));
+        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after)");
     }
     return o;
 }

@@ -166,3 +166,26 @@ def test_example_binary_matches_ctypes_path(example, ctx, tmp_path):
     r = ctx.render_whitted(sc, cam, prm, w, h) if example <= 2 else ctx.render_path(sc, cam, prm, w, h)
     assert np.array_equal(rgb, r["bgra"][:, :, 2::-1])
     assert (r["bgra"][:, :, 3] == 255).all()
+
+
+@pytest.mark.gpu
+def test_progressive_checkpointed_render_equals_one_shot(tmp_path):
+    """example04 --chunk/--checkpoint (host/Common/Progressive.hpp): 48 spp in passes of 10, interrupted after 20 and resumed
+    from the checkpoint, gives the one-shot frame (only the float summation order differs: +-1 LSB on a few pixels)."""
+    exe = _need(os.path.join(BIN, "example04"))
+    w, h, spp = 160, 120, 48
+    base = [exe, "--width", str(w), "--height", str(h), "--samples", str(spp), "--seed", "3"]
+    one, prog, ck = str(tmp_path / "one.ppm"), str(tmp_path / "prog.ppm"), str(tmp_path / "frame.ckpt")
+    subprocess.run(base + ["--out", one], check=True, capture_output=True, timeout=120)
+    p1 = subprocess.run(base + ["--chunk", "10", "--checkpoint", ck, "--stop-after", "20", "--out", str(tmp_path / "half.ppm")], check=True, capture_output=True, text=True, timeout=120)
+    assert "INFO: 20 of 48 samples per pixel done" in p1.stdout and os.path.getsize(ck) == 32 + w * h * 3 * 4
+    p2 = subprocess.run(base + ["--chunk", "10", "--checkpoint", ck, "--out", prog], check=True, capture_output=True, text=True, timeout=120)
+    assert "INFO: Resumed at sample 20" in p2.stdout and "INFO: 48 of 48 samples per pixel done" in p2.stdout
+    a, b = _read_ppm(one).astype(int), _read_ppm(prog).astype(int)
+    assert np.abs(a - b).max() <= 1 and (a != b).mean() < 0.01
+    half = _read_ppm(str(tmp_path / "half.ppm")).astype(float)     # the preview is exposed like the final frame, just noisier:
+    lin = lambda img: ((img / 255.0) ** 2).mean()                  # compare in linear light (undo the sqrt gamma; clipping aside)
+    assert abs(lin(half) - lin(a.astype(float))) < 0.1 * lin(a.astype(float))
+    # a checkpoint of another frame is refused
+    bad = subprocess.run(base[:-2] + ["--seed", "4", "--chunk", "10", "--checkpoint", ck], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "is not a checkpoint of this frame" in bad.stdout
