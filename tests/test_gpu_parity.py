@@ -242,6 +242,22 @@ def test_scene_specialised_kernel_matches_generic(ctx, which):
     assert ctx.last_path_kernel()[0] == 2 and np.array_equal(a["rgb"], c["rgb"])
 
 
+def test_specialisation_policy_and_cache_across_scenes(ctx):
+    """Default policy: first render of a scene -> generic kernel, second -> specialised (compiled once, then cached);
+    alternating scenes keep their own kernels and their own images."""
+    a_s, a_cam, a_prm = scenes.scene04(4, seed=21)
+    b_s, b_cam, b_prm = scenes.scene03(4, seed=22)
+    b_s.sphere(b_s.diffuse((0.3, 0.9, 0.3)), (0.3, 0.8, -1.2), 0.25)          # not a scene any other test renders
+    a_s.sphere(a_s.diffuse((0.9, 0.3, 0.3)), (3.0, 2.0, 1.0), 0.5)
+    kinds, imgs = [], {}
+    for name, (s, cam, prm) in [("a", (a_s, a_cam, a_prm)), ("b", (b_s, b_cam, b_prm))] * 3:
+        g = ctx.render_path(s, cam, prm, 96, 64)
+        kinds.append(ctx.last_path_kernel()[0])
+        assert np.array_equal(imgs.setdefault(name, g["rgb"]), g["rgb"])    # generic and specialised renders of a scene agree bit for bit
+    assert kinds == [1, 1, 2, 2, 2, 2]
+    assert not np.array_equal(imgs["a"], imgs["b"])
+
+
 def test_lds_and_global_scene_paths_agree(ctx):
     """The same small scene through the LDS-staged kernel and (debug flag) the global-memory kernel: identical images."""
     s, cam, prm = scenes.scene04(8, seed=5)
