@@ -172,6 +172,19 @@ const char* rt_last_error(const rt_ctx* ctx);   /* ctx may be NULL for rt_create
 int32_t rt_get_stats(const rt_ctx* ctx, rt_stats* out);
 int32_t rt_abi_version(void);
 
+/* Options of a context.  No counterpart in the reference.
+ * RT_OPT_ACCEL: how the path renders (rt_render_path, rt_path_accumulate_device) query the scene.
+ *   RT_ACCEL_NONE (default): brute force over every primitive in scene order, the reference's algorithm
+ *                            (03 Utils.h:255-271, 04 Utils.h:362-390) and the one the roofline figures are quoted on.
+ *   RT_ACCEL_BVH:            a bounding-volume hierarchy over spheres, rectangles, box faces and triangles (planes are
+ *                            tested by every ray).  Same image, bit for bit - exact ties (last element wins) and the
+ *                            sphere tMax rule (Common/Ray.hpp:127-134) included - in far fewer primitive tests on
+ *                            large scenes.  Whitted renders ignore it. */
+#define RT_OPT_ACCEL  1
+#define RT_ACCEL_NONE 0
+#define RT_ACCEL_BVH  1
+int32_t rt_set_option(rt_ctx* ctx, int32_t option, int32_t value);
+
 /* Fills params with the committed constants of the named example (1..4). */
 int32_t rt_whitted_params_default(int32_t example, rt_whitted_params* out);
 int32_t rt_path_params_default(int32_t example, rt_path_params* out);

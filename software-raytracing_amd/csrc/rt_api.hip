@@ -13,6 +13,7 @@
 #include "rt_device.h"
 #include "rt_kernels.h"
 #include "rt_jit.h"
+#include "rt_bvh.h"
 
 using namespace rt;
 
@@ -51,6 +52,7 @@ struct rt_ctx {
     std::string err;
     int regen_threshold_override = -1;
     int debug_flags = 0;
+    int accel = 0;                                // RT_OPT_ACCEL: 0 brute force (the reference's algorithm), 1 BVH
 };
 
 namespace {
@@ -80,11 +82,35 @@ struct HostScene {
     std::vector<size_t> slot_mat_fixups;  // indices into slots of the B records; B.w holds the material index until upload
     std::vector<int4> chunks;             // path scenes: {first slot byte offset (in the slot section), bytes, first run, n runs}
     int has_aa = 0;
+    std::vector<BvhItem> items;           // one per slot, in scene order: bounds for the optional BVH (rt_bvh.h)
+    Bvh bvh;
     // Appends one slot of n float4 already pushed to 'slots' to the run/chunk tables: runs never straddle a chunk, so a
     // scene too large for LDS can be walked chunk by chunk (k_path_tiled).
-    void add_slot(int dtype, size_t n_f4, int prim) {
+    void add_slot(int dtype, size_t n_f4, int prim, const float* tri = nullptr) {
         const int bytes = (int)(n_f4 * 16);
         const int start = (int)(slots.size() * 16) - bytes;
+        {
+            BvhItem it{}; it.ref = (uint32_t)start | (uint32_t)dtype; it.bounded = true;
+            const float4* S = slots.data() + slots.size() - n_f4;
+            if (dtype == PRIM_SPHERE) {
+                const float c[3] = {S[0].x, S[0].y, S[0].z}, r = sqrtf(S[0].w) * 1.000001f;
+                for (int a = 0; a < 3; ++a) { it.lo[a] = c[a] - r; it.hi[a] = c[a] + r; }
+            } else if (dtype == PRIM_RECT) {
+                // the rows x, y, z of the slot are orthonormal, so the points with in-plane coordinates (u, v) are
+                // p = x*(u - G1.w) + y*(v - G2.w) + z*G.w, |u| <= G3.x, |v| <= G3.y
+                const float4 &G = S[0], &G1 = S[4], &G2 = S[5], &G3 = S[6];
+                for (int a = 0; a < 3; ++a) { it.lo[a] = INFINITY; it.hi[a] = -INFINITY; }
+                for (int k = 0; k < 4; ++k) {
+                    const float u = ((k & 1) ? G3.x : -G3.x) - G1.w, v = ((k & 2) ? G3.y : -G3.y) - G2.w;
+                    const float p[3] = {G1.x * u + G2.x * v + G.x * G.w, G1.y * u + G2.y * v + G.y * G.w, G1.z * u + G2.z * v + G.z * G.w};
+                    for (int a = 0; a < 3; ++a) { it.lo[a] = std::min(it.lo[a], p[a]); it.hi[a] = std::max(it.hi[a], p[a]); }
+                }
+            } else if (dtype == PRIM_TRI && tri) {
+                for (int a = 0; a < 3; ++a) { it.lo[a] = std::min(tri[a], std::min(tri[3 + a], tri[6 + a])); it.hi[a] = std::max(tri[a], std::max(tri[3 + a], tri[6 + a])); }
+            } else it.bounded = false;       // planes
+            for (int a = 0; a < 3; ++a) if (!std::isfinite(it.lo[a]) || !std::isfinite(it.hi[a])) it.bounded = false;
+            items.push_back(it);
+        }
         bool new_chunk = chunks.empty() || chunks.back().y + bytes > RT_TILE_BYTES;
         if (new_chunk) chunks.push_back(make_int4(start, 0, (int)sruns.size(), 0));
         if (!new_chunk && !sruns.empty() && sruns.back().x == dtype) sruns.back().z++;
@@ -221,7 +247,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
             H.slots.push_back(G); H.slots.push_back(A); H.slot_mat_fixups.push_back(H.slots.size()); H.slots.push_back(B); H.slots.push_back(C);
             if (wide) { H.slots.push_back(G1); H.slots.push_back(G2); H.slots.push_back(G3); H.slots.push_back(f4(0, 0, 0, 0)); }
             // rectangles and triangles share one loop in the kernel but not one run: the run type picks the inside test
-            H.add_slot(dtype, wide ? 8 : 4, i);
+            H.add_slot(dtype, wide ? 8 : 4, i, P.type == RT_PRIM_TRIANGLE ? f : nullptr);
             if (variant != 0) { H.info.push_back(make_int4(dtype, 0, mat, (int)P.flags)); continue; }
             dtype = P.type;
         }
@@ -263,7 +289,8 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     // one spare zero record after the runs: the path kernels prefetch runs[r + 1]
     size_t o_runs = 0, o_sruns = pad(o_runs + (H.runs.size() + 1) * 16), o_chunks = pad(o_sruns + (H.sruns.size() + 1) * 16), o_geom = pad(o_chunks + H.chunks.size() * 16), o_info = pad(o_geom + H.geom.size() * 16),
            o_slots = pad(o_info + (H.path ? 0 : H.info.size()) * 16), o_mats = pad(o_slots + H.slots.size() * 16),
-           o_lights = pad(o_mats + H.mats.size() * 16), total = pad(o_lights + H.lights.size() * 16 + 16);
+           o_lights = pad(o_mats + H.mats.size() * 16), o_bnodes = pad(o_lights + H.lights.size() * 16 + 16), o_brefs = pad(o_bnodes + H.bvh.nodes.size() * 16),
+           o_bunb = pad(o_brefs + H.bvh.refs.size() * 4), total = pad(o_bunb + H.bvh.unbounded.size() * 4 + 16);
     if (total > c->h_stage_cap) {
         if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
         c->h_stage = nullptr; c->h_stage_cap = 0;
@@ -290,6 +317,13 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     }
     memcpy(h + o_mats, H.mats.data(), H.mats.size() * 16);
     memcpy(h + o_lights, H.lights.data(), H.lights.size() * 16);
+    {   // slot-section offsets -> blob byte offsets (the low bits carry the device type)
+        memcpy(h + o_bnodes, H.bvh.nodes.data(), H.bvh.nodes.size() * 16);
+        uint32_t* r = reinterpret_cast<uint32_t*>(h + o_brefs);
+        for (size_t k = 0; k < H.bvh.refs.size(); ++k) r[k] = H.bvh.refs[k] + (uint32_t)o_slots;
+        r = reinterpret_cast<uint32_t*>(h + o_bunb);
+        for (size_t k = 0; k < H.bvh.unbounded.size(); ++k) r[k] = H.bvh.unbounded[k] + (uint32_t)o_slots;
+    }
     HIPCHK(c, hipMemcpyAsync(c->scene_buf.p, h, total, hipMemcpyHostToDevice, st));
     D.blob = (const float4*)c->scene_buf.p;
     D.off_runs = (int)(o_runs / 16); D.off_geom = (int)(o_geom / 16); D.off_info = (int)(o_info / 16);
@@ -304,6 +338,8 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
         D.srun_pack[r / 4] |= (unsigned long long)(((uint32_t)H.sruns[r].x | ((uint32_t)H.sruns[r].z << 3)) & 0xFFFFU) << ((r % 4) * 16);
     }
     D.off_sruns = (int)(o_sruns / 16); D.n_sruns = (int)H.sruns.size(); D.slot_bytes = (int)(H.slots.size() * 16);
+    D.off_bvh_nodes = (int)(o_bnodes / 16); D.off_bvh_refs = (int)(o_brefs / 16); D.off_bvh_unbounded = (int)(o_bunb / 16);
+    D.n_bvh_refs = (int)H.bvh.refs.size(); D.n_bvh_unbounded = (int)H.bvh.unbounded.size(); D.bvh_depth = H.bvh.depth; D.n_bvh_nodes = (int)H.bvh.nodes.size() / 4;
     return RT_OK;
 }
 
@@ -398,6 +434,16 @@ int32_t rt_path_params_default(int32_t example, rt_path_params* out) {
     return RT_OK;
 }
 
+int32_t rt_set_option(rt_ctx* c, int32_t option, int32_t value) {
+    if (!c) return RT_ERR_BAD_ARG;
+    if (option == RT_OPT_ACCEL) {
+        if (value != RT_ACCEL_NONE && value != RT_ACCEL_BVH) return fail(c, RT_ERR_BAD_ARG, "RT_OPT_ACCEL: value must be RT_ACCEL_NONE or RT_ACCEL_BVH");
+        c->accel = value;
+        return RT_OK;
+    }
+    return fail(c, RT_ERR_BAD_ARG, "rt_set_option: unknown option " + std::to_string(option));
+}
+
 int32_t rt_sync(rt_ctx* c, void* stream) {
     int rc = check_ctx(c); if (rc) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -426,6 +472,11 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     HostScene H; DevScene D;
     if ((rc = compile_scene(c, scene, p->variant, H))) return rc;
+    const bool accel = c->accel == 1;
+    if (accel) {
+        build_bvh(H.items, H.bvh);
+        if (H.bvh.depth > RT_BVH_STACK) return fail(c, RT_ERR_TOO_LARGE, "BVH deeper than the traversal stack (" + std::to_string(H.bvh.depth) + " > " + std::to_string(RT_BVH_STACK) + ")");
+    }
     if ((rc = upload_scene(c, H, st, D))) return rc;
 
     PathArgs A{};
@@ -434,7 +485,7 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     A.debug_flags = c->debug_flags;
     // camera code costs about as much as testing 20 primitives: with few primitives wait for a batch of idle lanes,
     // with many refill every idle lane at once (measured: tools/sweep_regen.py, tools/sweep_regen_stress.py)
-    A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : (scene->n_prims >= 128 ? 1 : 16);
+    A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : ((accel || scene->n_prims >= 128) ? 1 : 16);
     float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 03 Main.cpp:317
     float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
     A.inv_w2 = 2.0f / w; A.inv_h2 = 2.0f / h; A.kx = th * w / h; A.ky = th;
@@ -453,11 +504,12 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     hipFunction_t jit = nullptr;
     const char* jit_env = getenv("RT_MI355_JIT");
     c->jit_note.clear();
-    if (!(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
+    if (!accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
         jit = jit_path_kernel(p->variant, H.slots, H.sruns, c->jit_note);
-    c->last_path_kernel = jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0);
-    launch_path(p->variant, D, A, target, slices, c->d_counters, st, jit);
+    c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));
+    if (accel) { c->jit_note = "BVH walk (RT_OPT_ACCEL)"; launch_path_bvh(p->variant, D, A, target, slices, c->d_counters, st); }
+    else launch_path(p->variant, D, A, target, slices, c->d_counters, st, jit);
     HIPCHK(c, hipGetLastError());
     if (slices > 1) { launch_sum_slices((const float4*)c->partial.p, (int)npx, slices, (float4*)d_accum, st); HIPCHK(c, hipGetLastError()); }
     c->pending_samples = (uint64_t)npx * (uint64_t)n_samples;
@@ -554,6 +606,57 @@ int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, i
     hipFunction_t fn = jit_path_kernel(variant, H.slots, H.sruns, n);
     if (note && cap > 0) { strncpy(note, n.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
     return fn ? 1 : 0;
+}
+// rt_debug_bvh_probe: builds the BVH of a scene on the host (no GPU needed) and checks it: every bounded slot is referenced by
+// exactly one leaf whose box contains the slot's padded box, every child box lies inside its parent's, leaves hold at most
+// RT_BVH_LEAF entries.  out[0..4] = {nodes, leaf entries, unbounded slots, depth, slots}.  Returns 0, or the number of violations.
+int32_t rt_debug_bvh_probe(const rt_scene* scene, int32_t variant, int32_t* out) {
+    HostScene H;
+    int rc = compile_scene(nullptr, scene, variant, H);
+    if (rc) return rc;
+    std::vector<BvhItem> items = H.items;
+    build_bvh(items, H.bvh);
+    const Bvh& B = H.bvh;
+    int bad = 0;
+    std::vector<int> seen(H.slots.size() / 4 + 1, 0);
+    const int n_nodes = (int)B.nodes.size() / 4;
+    auto inside = [](const float4& lo, const float4& hi, const float* ilo, const float* ihi) {
+        return lo.x <= ilo[0] && lo.y <= ilo[1] && lo.z <= ilo[2] && hi.x >= ihi[0] && hi.y >= ihi[1] && hi.z >= ihi[2]; };
+    std::vector<int> visits(n_nodes, 0);
+    for (int k = 0; k < n_nodes; ++k) {
+        for (int ch = 0; ch < 2; ++ch) {
+            const float4 lo = B.nodes[4 * k + 2 * ch], hi = B.nodes[4 * k + 2 * ch + 1];
+            const uint32_t ref = __builtin_bit_cast(uint32_t, ch ? B.nodes[4 * k + 1].w : B.nodes[4 * k].w);
+            if (ch == 1 && (ref & 0x80000000U) && ref == __builtin_bit_cast(uint32_t, B.nodes[4 * k].w)) continue;   // single-leaf root: both children are that leaf
+            if (!(ref & 0x80000000U)) {
+                if ((int)ref >= n_nodes || (int)ref <= k) { ++bad; continue; }      // children come after their parent
+                visits[ref]++;
+                for (int g = 0; g < 2; ++g) {             // grandchildren boxes lie inside this child's box
+                    const float4 gl = B.nodes[4 * ref + 2 * g], gh = B.nodes[4 * ref + 2 * g + 1];
+                    const float l[3] = {gl.x, gl.y, gl.z}, h[3] = {gh.x, gh.y, gh.z};
+                    if (!inside(lo, hi, l, h)) ++bad;
+                }
+            } else {
+                const uint32_t first = (ref & 0x7fffffffU) >> 3, n = (ref & 7U) + 1U;
+                if (n > RT_BVH_LEAF || first + n > B.refs.size()) { ++bad; continue; }
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t r = B.refs[first + i];
+                    seen[(r & ~63U) / 64]++;
+                    for (const BvhItem& it : H.items)      // the unpadded box of the slot must lie inside the leaf's
+                        if (it.ref == r && !inside(lo, hi, it.lo, it.hi)) ++bad;
+                }
+            }
+        }
+    }
+    for (int k = 1; k < n_nodes; ++k) if (visits[k] != 1) ++bad;    // a tree: every inner node but the root has one parent
+    int n_bounded = 0;
+    for (const BvhItem& it : H.items) {
+        if (it.bounded) { ++n_bounded; if (seen[(it.ref & ~63U) / 64] != 1) ++bad; }
+        else if (seen[(it.ref & ~63U) / 64] != 0) ++bad;
+    }
+    if ((int)B.refs.size() != n_bounded || B.unbounded.size() + B.refs.size() != H.items.size()) ++bad;
+    if (out) { out[0] = n_nodes; out[1] = (int)B.refs.size(); out[2] = (int)B.unbounded.size(); out[3] = B.depth; out[4] = (int)H.items.size(); }
+    return bad;
 }
 int32_t rt_debug_set_flags(rt_ctx* c, int32_t f) { if (!c) return RT_ERR_BAD_ARG; c->debug_flags = f; return RT_OK; }
 int32_t rt_debug_set_regen_threshold(rt_ctx* c, int32_t n) { if (!c) return RT_ERR_BAD_ARG; c->regen_threshold_override = n; return RT_OK; }

@@ -6,6 +6,7 @@
 #endif
 
 #define RT_LDS_SCENE_MAX_BYTES (48 * 1024)
+#define RT_BVH_STACK 48   /* optional BVH walk: per-lane stack entries in LDS; the builder refuses deeper trees */
 
 namespace rt {
 // Ray counters: one 64-bit atomic per wave and counter; 130k waves hitting ONE address cost ~3 ms at 4K (the whole 01

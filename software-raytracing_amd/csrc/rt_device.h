@@ -37,6 +37,9 @@ struct DevScene {
     int whitted_branches;                 // Whitted scenes: some material spawns reflection AND refraction at one hit (needs the LDS stack)
     int off_sruns, n_sruns, slot_bytes;   // the runs over the slot section (the 'runs' above belong to the Whitted layout)
     int off_chunks, n_chunks;   // path scenes: int4 {blob byte offset, bytes, first run, n runs} per <= RT_TILE_BYTES piece of the slots
+    // optional BVH (rt_bvh.h, rt_bvh_device.h): float4 offsets of the node pairs, of the leaf entries and of the list of
+    // unbounded slots (planes); entries are uint32 {blob byte offset of the slot | device type}
+    int off_bvh_nodes, off_bvh_refs, off_bvh_unbounded, n_bvh_refs, n_bvh_unbounded, bvh_depth, n_bvh_nodes;
 };
 
 // Section pointers over either the global blob (wave-uniform reads become scalar loads) or its LDS copy

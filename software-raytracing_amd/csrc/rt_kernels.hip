@@ -4,6 +4,7 @@
 #include "rt_strict.h"
 #include "rt_kernels.h"
 #include "rt_path_device.h"
+#include "rt_bvh_device.h"
 
 namespace rt {
 
@@ -36,6 +37,19 @@ static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int
 void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
     if (variant == 3) launch_path_v<3>(S, A, out, n_slices, counters, st, jit);
     else              launch_path_v<4>(S, A, out, n_slices, counters, st, jit);
+}
+
+// Optional BVH walk (rt_set_option(RT_OPT_ACCEL, RT_ACCEL_BVH)): same bounce loop, the scene query walks a tree.
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_path_bvh(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    path_bvh_body<VARIANT>(SD, A, out, counters);
+}
+void launch_path_bvh(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st) {
+    dim3 grid(((A.width + 15) / 16) * ((A.height + 15) / 16), n_slices);
+    // the walk is bound by the latency of dependent fetches, so resident waves matter: the per-lane stack takes only what this tree needs
+    const size_t lds = (size_t)(S.bvh_depth > 0 ? S.bvh_depth : 1) * 256 * sizeof(uint32_t);
+    if (variant == 3) hipLaunchKernelGGL((k_path_bvh<3>), grid, dim3(256), lds, st, S, A, out, counters);
+    else              hipLaunchKernelGGL((k_path_bvh<4>), grid, dim3(256), lds, st, S, A, out, counters);
 }
 
 // Sum the per-slice partial images in a fixed order (deterministic), out = float4(sum rgb, samples).

@@ -26,6 +26,7 @@ int main(int argc, char* argv[]) {
         if (!opt.dump.empty()) { rtbackend::Flat flat; path_detail::flatten(scene.getElements(), &flat); DumpFlat(flat, opt.dump); return 0; }
 
         rtbackend::context();   // device / library initialisation is not part of the render time reported below
+        if (opt.bvh) rtbackend::check(rt_set_option(rtbackend::context(), RT_OPT_ACCEL, RT_ACCEL_BVH));
         auto renderBeginTime = std::chrono::system_clock::now();
         Render(&frameBuffer, scene, 50.0f, opt.samples, {-2.0f, 1.5f, 1.0f}, {-30.0f, -42.0f, 0.0f});
         std::cout << "INFO: Scene rendered in " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - renderBeginTime).count() << " ms." << std::endl;

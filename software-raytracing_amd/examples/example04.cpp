@@ -35,6 +35,7 @@ int main(int argc, char* argv[]) {
         if (!opt.dump.empty()) { rtbackend::Flat flat; path_detail::flatten(scene.getElements(), &flat); DumpFlat(flat, opt.dump); return 0; }
 
         rtbackend::context();   // device / library initialisation is not part of the render time reported below
+        if (opt.bvh) rtbackend::check(rt_set_option(rtbackend::context(), RT_OPT_ACCEL, RT_ACCEL_BVH));
         auto renderBeginTime = std::chrono::system_clock::now();
         if (opt.chunk) {
             // progressive: --chunk samples per pass, the running sums kept in --checkpoint so that an interrupted run

@@ -13,6 +13,7 @@ struct Options {
     unsigned width = 784, height = 561, samples = 0, seed = 1;
     std::string out, dump, checkpoint;
     unsigned chunk = 0, stopAfter = 0;   // progressive rendering: samples per pass, stop early (to be resumed)
+    bool bvh = false;                    // 03/04: query the scene through the optional BVH (same image, fewer primitive tests)
 };
 
 inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
@@ -24,7 +25,8 @@ inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
             if (i + 1 >= argc) throw std::runtime_error(std::string("ERROR: missing value after ") + name);
             return argv[++i];
         };
-        if (const char* v = value("--width")) o.width = static_cast<unsigned>(std::atoi(v));
+        if (std::strcmp(argv[i], "--bvh") == 0) o.bvh = true;
+        else if (const char* v = value("--width")) o.width = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--height")) o.height = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--samples")) o.samples = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--seed")) o.seed = static_cast<unsigned>(std::strtoul(v, nullptr, 10));
@@ -33,7 +35,7 @@ inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
         else if (const char* v = value("--checkpoint")) o.checkpoint = v;
         else if (const char* v = value("--chunk")) o.chunk = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--stop-after")) o.stopAfter = static_cast<unsigned>(std::atoi(v));
-        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after)");
+        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after --bvh)");
     }
     return o;
 }

@@ -9,6 +9,7 @@ RT_ERR_NO_DEVICE = -4
 RT_ERR_TOO_LARGE = -5
 
 RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_RECT, RT_PRIM_TRIANGLE, RT_PRIM_BOX = 0, 1, 2, 3, 4
+RT_OPT_ACCEL, RT_ACCEL_NONE, RT_ACCEL_BVH = 1, 0, 1
 RT_PRIM_FLAG_FLIP_NORMALS = 1
 RT_MAT_PHONG, RT_MAT_DIFFUSE, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_LIGHT = 0, 1, 2, 3, 4
 RT_PATH_SKY, RT_PATH_LIGHTS = 3, 4
@@ -69,5 +70,5 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_get_stats", "rt_abi_version",
     "rt_whitted_params_default", "rt_path_params_default",
     "rt_render_whitted", "rt_render_path",
-    "rt_path_accumulate_device", "rt_whitted_device", "rt_resolve_device", "rt_sync",
+    "rt_path_accumulate_device", "rt_whitted_device", "rt_resolve_device", "rt_sync", "rt_set_option",
 ]

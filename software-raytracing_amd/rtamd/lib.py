@@ -43,6 +43,7 @@ def load():
         L.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.rt_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.rt_debug_set_regen_threshold.argtypes = [C.c_void_p, C.c_int32]
         L.rt_debug_set_flags.argtypes = [C.c_void_p, C.c_int32]
         L.rt_debug_last_path_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
@@ -113,6 +114,9 @@ class Context:
     def sync(self, stream=None):
         self._chk(self.L.rt_sync(self.h, stream))
         return self.stats()
+
+    def set_option(self, option, value):
+        self._chk(self.L.rt_set_option(self.h, option, value))
 
     def set_regen_threshold(self, n):
         self._chk(self.L.rt_debug_set_regen_threshold(self.h, n))

@@ -5,7 +5,7 @@ import re
 
 import pytest
 
-from rtamd import abi, lib
+from rtamd import abi, lib, scenes
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
@@ -81,3 +81,35 @@ def test_scene_specialised_kernel_source_compiles_for_every_primitive_type():
     big = scenes.scene_stress(n_spheres=80, grid=2, spp=1)[0]
     note = C.create_string_buffer(1024); sc = big.c()
     assert L.rt_debug_jit_probe(C.byref(sc), 4, note, 1024) == 0 and b"specialised up to 64" in note.value
+
+
+def test_bvh_builder_covers_every_bounded_slot_exactly_once():
+    """Host logic of the optional BVH (rt_bvh.h), no GPU: rt_debug_bvh_probe builds the tree and checks that every bounded
+    slot sits in exactly one leaf whose box contains it, child boxes nest, planes stay outside the tree; here on the stress
+    scene, the reference scenes, boxes (six rectangle slots each), a single primitive, planes only and an empty scene."""
+    L = lib.load()
+    L.rt_debug_bvh_probe.argtypes = [C.POINTER(abi.rt_scene), C.c_int32, C.POINTER(C.c_int32)]
+
+    def probe(s):
+        sc = s.c(); out = (C.c_int32 * 5)()
+        assert L.rt_debug_bvh_probe(C.byref(sc), 4, out) == 0
+        return dict(nodes=out[0], refs=out[1], unbounded=out[2], depth=out[3], slots=out[4])
+
+    r = probe(scenes.scene_stress(spp=1)[0])
+    assert r["slots"] == 10000 + 1 + 8192 + 1 and r["unbounded"] == 1 and r["refs"] == r["slots"] - 1
+    assert r["refs"] / 4 <= r["nodes"] + 1 <= r["refs"] and r["depth"] <= 24
+    r = probe(scenes.scene04(4)[0]); assert (r["refs"], r["unbounded"], r["nodes"]) == (4, 5, 1)
+    s = scenes.Scene(); w = s.diffuse((0.5, 0.5, 0.5))
+    r = probe(s); assert (r["refs"], r["unbounded"], r["nodes"]) == (0, 0, 0)
+    s.plane(w, (0, 0, 0), (0, 1, 0)); s.plane(w, (0, 0, -8), (0.1, 0.2, 1.0))
+    r = probe(s); assert (r["refs"], r["unbounded"], r["nodes"]) == (0, 2, 0)
+    s.sphere(w, (0, 1, -3), 1.0)
+    r = probe(s); assert (r["refs"], r["unbounded"], r["nodes"], r["depth"]) == (1, 2, 1, 1)
+    for k in range(7):
+        s.box(w, (3 * k, 0, -5), (1, 2, 3), (10 * k, 20, 5 * k)); s.triangle(w, (k, 0, 0), (k + 1, 0, 0), (k, 1, -k))
+    r = probe(s); assert r["refs"] == 1 + 7 * 6 + 7 and r["unbounded"] == 2
+    # many coincident primitives: no spatial split exists, the object-median fallback must still terminate
+    s = scenes.Scene(); w = s.diffuse((0.5, 0.5, 0.5))
+    for k in range(300):
+        s.sphere(w, (1, 2, 3), 0.5)
+    r = probe(s); assert r["refs"] == 300 and r["depth"] <= 10
