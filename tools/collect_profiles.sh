@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): the bench line, a kernel-trace pass and three PMC passes (each its own run, as
+# Runs on the GPU box (via gpurun): the bench line, a kernel-trace pass and four PMC passes (each its own run, as
 # the MI355X guide prescribes), all under gpurun_out/prof/.  tools/make_profile_json.py turns them into profiles/.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
@@ -9,4 +9,5 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_write -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --output-format csv -d $OUT/pmc_flops -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_flops.json 2> $OUT/pmc_flops.err || exit 1
 find $OUT -name "*.csv" | head -20
