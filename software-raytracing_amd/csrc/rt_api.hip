@@ -45,7 +45,8 @@ struct rt_ctx {
     unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
     unsigned long long* h_counters = nullptr;     // pinned
     std::string jit_note;                         // why the last path render was not scene-specialised ("" = it was)
-    int last_path_kernel = -1;                    // 2 specialised, 1 generic LDS-resident, 0 tiled / global
+    int last_path_kernel = -1;                    // 3 BVH walk, 2 specialised, 1 generic LDS-resident, 0 tiled / global
+    int last_whitted_kernel = -1;                 // 2 specialised (02 only), 1 generic
     void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned scene staging
     uint64_t pending_samples = 0;
     rt_stats stats{};
@@ -498,7 +499,6 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     size_t npx = (size_t)width * height;
     float4* target = (float4*)d_accum;
     if (slices > 1) { HIPCHK(c, c->partial.reserve(npx * slices * sizeof(float4))); target = (float4*)c->partial.p; }
-    if ((rc = begin_timed(c, st))) return rc;
     // small scenes: the scene query compiled for THIS scene (literal operands, no loops); debug flag 8 or RT_MI355_JIT=0 keeps
     // the generic kernel, debug flag 16 or RT_MI355_JIT=2 specialises at the first render (A/B and parity tests); an unavailable hiprtc is not an error, the generic kernel renders the same image
     hipFunction_t jit = nullptr;
@@ -507,6 +507,7 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     if (!accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
         jit = jit_path_kernel(p->variant, H.slots, H.sruns, c->jit_note);
+    if ((rc = begin_timed(c, st))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
     c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));
     if (accel) { c->jit_note = "BVH walk (RT_OPT_ACCEL)"; launch_path_bvh(p->variant, D, A, target, slices, c->d_counters, st); }
     else launch_path(p->variant, D, A, target, slices, c->d_counters, st, jit);
@@ -534,8 +535,18 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
     float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 01 Main.cpp:333
     float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
     A.w = w; A.h = h; A.tan_half = th;
-    if ((rc = begin_timed(c, st))) return rc;
-    launch_whitted(p->shadow_samples > 0, D, A, (float4*)d_color, c->d_counters, st);
+    // 02: nearly every ray is a shadow sample; for small scenes their scene query is compiled for THIS scene like the path
+    // kernels' (same policy, same switches: second render of a scene, a large job, debug flag 16 / RT_MI355_JIT=2; flag 8 / =0 off)
+    hipFunction_t jit = nullptr;
+    const char* jit_env = getenv("RT_MI355_JIT");
+    c->jit_note.clear();
+    if (p->shadow_samples > 0 && !(c->debug_flags & 8) && !(jit_env && jit_env[0] == '0') &&
+        jit_wanted(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, (double)width * height * p->shadow_samples * (scene->n_lights > 0 ? scene->n_lights : 1),
+                   (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
+        jit = jit_path_kernel(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, c->jit_note);
+    c->last_whitted_kernel = jit ? 2 : 1;
+    if ((rc = begin_timed(c, st))) return rc;      // after a possible compile
+    launch_whitted(p->shadow_samples > 0, D, A, (float4*)d_color, c->d_counters, st, jit);
     HIPCHK(c, hipGetLastError());
     c->pending_samples = (uint64_t)width * height;
     return end_timed(c, st);
@@ -598,9 +609,11 @@ int32_t rt_debug_last_path_kernel(const rt_ctx* c, char* note, int32_t cap) {
     if (note && cap > 0) { strncpy(note, c->jit_note.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
     return c->last_path_kernel;
 }
+int32_t rt_debug_last_whitted_kernel(const rt_ctx* c) { return c ? c->last_whitted_kernel : -1; }
+// variant 3 / 4: the path kernels; 2: the 02 kernel (a Whitted scene)
 int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, int32_t cap) {
     HostScene H;
-    int rc = compile_scene(nullptr, scene, variant, H);
+    int rc = compile_scene(nullptr, scene, variant == RT_JIT_WHITTED_SOFT ? 0 : variant, H);
     if (rc) return rc;
     std::string n;
     hipFunction_t fn = jit_path_kernel(variant, H.slots, H.sruns, n);

@@ -5,6 +5,7 @@
 #include <vector>
 
 namespace rt {
+constexpr int RT_JIT_WHITTED_SOFT = 2;   // 'variant' of the 02 kernel (3 and 4 are the path variants)
 // Returns the kernel for this (variant, slot section) or nullptr when specialisation is unavailable (hiprtc missing, compile
 // error, scene too large); 'note' then says why.  Compiled kernels are cached per process by the hash of their source.
 // Policy: whether this render should use (and, if need be, compile) the specialised kernel; counts sightings of the scene.

@@ -28,6 +28,12 @@ const char* const kSrcDevice =
 const char* const kSrcPath =
 #include "rt_jit_src_path.inc"
     ;
+const char* const kSrcStrict =
+#include "rt_jit_src_strict.inc"
+    ;
+const char* const kSrcWhitted =
+#include "rt_jit_src_whitted.inc"
+    ;
 
 constexpr int RT_JIT_MAX_PRIMS = 64;
 
@@ -113,9 +119,16 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     size_t n_prims = 0;
     for (const int4& r : sruns) n_prims += (size_t)r.z;
     if (n_prims == 0 || n_prims > RT_JIT_MAX_PRIMS) { note = "scene has " + std::to_string(n_prims) + " slots (specialised up to " + std::to_string(RT_JIT_MAX_PRIMS) + ")"; return nullptr; }
-    std::string src = std::string("#define RT_JIT_SCENE 1\ntypedef unsigned int uint32_t; typedef unsigned char uint8_t; typedef unsigned long long uint64_t; typedef unsigned long uintptr_t;\n") + kSrcArgs + "\n" + kSrcDevice + "\n" + gen_closest_hit(slots, sruns) + kSrcPath +
-        "\nextern \"C\" __global__ __launch_bounds__(256) void k_path_jit(rt::DevScene SD, rt::PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
-        "    rt::path_body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
+    std::string src = std::string("#define RT_JIT_SCENE 1\ntypedef unsigned int uint32_t; typedef unsigned char uint8_t; typedef unsigned long long uint64_t; typedef unsigned long uintptr_t;\n") + kSrcArgs + "\n" + kSrcDevice + "\n" + gen_closest_hit(slots, sruns);
+    const char* entry = variant == RT_JIT_WHITTED_SOFT ? "k_whitted_jit" : "k_path_jit";
+    if (variant == RT_JIT_WHITTED_SOFT)   // 02: the generated query serves the shadow samples of whitted_body<true>
+        src += std::string(kSrcStrict) + "\n" + kSrcWhitted +
+            "\nextern \"C\" __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted_jit(rt::DevScene SD, rt::WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
+            "    rt::whitted_body<true>(SD, A, out, counters);\n}\n";
+    else
+        src += std::string(kSrcPath) +
+            "\nextern \"C\" __global__ __launch_bounds__(256) void k_path_jit(rt::DevScene SD, rt::PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
+            "    rt::path_body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
     int dev = 0; (void)hipGetDevice(&dev);
     const auto key = std::make_pair(dev, fnv1a(src));
     std::lock_guard<std::mutex> lock(g_mu);
@@ -126,7 +139,8 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rt_path_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) e.note = "hiprtcCreateProgram failed";
     else {
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize"};
+        // same code generation as the Makefile's: contraction on (rt_strict.h turns it off for itself), '/' and sqrtf correctly rounded
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt"};
         hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
         if (r != HIPRTC_SUCCESS) {
             size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
@@ -139,7 +153,7 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
                 if (FILE* f = fopen((std::string(dump) + ".hip").c_str(), "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
                 if (FILE* f = fopen((std::string(dump) + ".co").c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
             }
-            if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, "k_path_jit") != hipSuccess) { e.fn = nullptr; e.note = "hipModuleLoadData/GetFunction failed"; }
+            if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, entry) != hipSuccess) { e.fn = nullptr; e.note = "hipModuleLoadData/GetFunction failed"; }
         }
         hiprtcDestroyProgram(&prog);
     }

@@ -4,6 +4,7 @@
 #include "rt_strict.h"
 #include "rt_kernels.h"
 #include "rt_path_device.h"
+#include "rt_whitted_device.h"
 #include "rt_bvh_device.h"
 
 namespace rt {
@@ -70,150 +71,27 @@ void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* o
 // walked depth-first with a scalar weight per node; the one pending sibling per depth level lives
 // in an LDS slot indexed by depth (bounded by max_depth), never in scratch memory.
 // =================================================================================================
-#define WBLOCK 128
-template <bool SOFT>
 // 8 waves/SIMD (64 VGPRs, a few cold values spilled): this kernel is bound by dependent-issue latency, not registers:
 // measured 02 4K/256 samples 10.5 ms at 4 waves, 9.3 at 5, 8.7 at 6, 8.3 at 8
+template <bool SOFT>
 __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
-    const Scn S = scn_over(SD, SD.blob);
-    // slot k (k = depth of the parked child, 1..max_depth+1): o(3) d(3) weight node, one column per thread; sized by the
-    // launch to max_depth + 2 slots (4 KB each), so the default depth 4 leaves room for 6 blocks per CU
-    extern __shared__ float stk_raw[];
-    float (*stk)[8][WBLOCK] = reinterpret_cast<float (*)[8][WBLOCK]>(stk_raw);
-    // 02: the shadow samples (almost all of its rays) run on the slot layout staged in LDS behind the stack, with the
-    // fast tests of the path kernels (see fastshadow in rt_strict.h for why that is safe); A.shadow_lds = 0 when the
-    // scene is too large for that
-    const SceneMem<true> T{reinterpret_cast<const char*>(stk_raw)};
-    const uint32_t sh_slots = T.at((uint32_t)A.stack_bytes);
-    const int4* __restrict__ sruns = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
-    if (SOFT && A.shadow_lds) {
-        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(stk_raw) + A.stack_bytes);
-        const float4* src = SD.blob + SD.off_slots;
-        for (int i = threadIdx.x; i < (SD.slot_bytes >> 4); i += WBLOCK) dst[i] = src[i];
-        __syncthreads();
-    }
-    const int tid = threadIdx.x;
-    // 16x8 pixels per 128-thread block, 8x8 per wave
-    int tiles_x = (A.width + 15) >> 4;
-    int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    int px = tx * 16 + (tid >> 6) * 8 + (tid & 7), py = ty * 8 + ((tid & 63) >> 3);
-    bool inside = px < A.width && py < A.height;
-    const uint32_t pixel = (uint32_t)(py * A.width + px);
-    const uint32_t skey = rng_sample_key(rng_pixel_key(A.seed, pixel), 0U);
-
-    f3 o = F3(0, 0, 0), d = strict::primary_dir(px, py, A.w, A.h, A.tan_half);     // 01 Main.cpp:340-344
-    float weight = 1.0f, tmin = 0.0f;
-    int depth = 0;
-    uint32_t node = 1U, pending = 0U;
-    f3 acc = F3(0, 0, 0);
-    unsigned int rays = 0, srays = 0;
-    bool active = inside;
-    const f3 sky = F3(0.2f, 0.7f, 0.8f);
-
-    while (__any(active)) {
-        if (active) {
-            bool done_node = true;   // pop after this node unless a child continues in place
-            float t; int idx = -1;
-            if (depth <= A.max_depth) { ++rays; idx = strict::closest_hit(S, o, d, tmin, 1000.0f, t); }          // :386-403
-            if (idx < 0) {
-                acc = madd(sky, weight, acc);                                                            // :489-493
-            } else {
-                int4 inf = S.info[idx];
-                f3 p = strict::add(o, strict::muls(d, t));                                               // :414
-                f3 n = (inf.x == PRIM_SPHERE) ? strict::normalize(strict::sub(p, F3(S.geom[inf.y]))) : F3(S.geom[inf.y]);   // Sphere.hpp:48, Plane.hpp:48
-                float4 m0 = S.mats[inf.z * 3], m1 = S.mats[inf.z * 3 + 1], m2 = S.mats[inf.z * 3 + 2];
-                float p2s = m1.z, r2r = m1.w;
-                float wp = fmaxf(1.0f - p2s, 0.0f), wr = fmaxf(1.0f - r2r, 0.0f);
-                if (p2s > 0.0f) {                                                                        // :421-447
-                    f3 diffuse = F3(0, 0, 0), specular = F3(0, 0, 0);
-                    for (int li = 0; li < S.n_lights; ++li) {
-                        float4 l0 = S.lights[2 * li], l1 = S.lights[2 * li + 1];
-                        f3 lp = F3(l0);
-                        f3 to = strict::sub(lp, p);
-                        f3 tod = strict::normalize(to);
-                        float len = strict::length(to);
-                        float intensity = 1.0f;
-                        bool skip = false;
-                        if (!SOFT) {                                                                     // 01 :435-436
-                            if (depth + 1 <= A.max_depth) { ++srays; skip = strict::any_hit(S, p, tod, 0.01f, len); }
-                        } else if (depth + 1 <= A.max_depth) {                                           // 02 :452-467, :539-566
-                            float per = 1.0f / (float)A.shadow_samples;
-                            float tmax_s = len - l0.w;
-                            for (int i = 0; i < A.shadow_samples; ++i) {
-                                uint32_t c = ((node * (uint32_t)S.n_lights + (uint32_t)li) * (uint32_t)A.shadow_samples + (uint32_t)i) * 4U;
-                                float u0, u1, u2, u3;
-                                rng_pair(skey, c, u0, u1); rng_pair(skey, c + 2U, u2, u3);
-                                f3 sd = fastshadow::to_light_disk(p, lp, tod, l0.w, u0, u1, u2, u3);
-                                ++srays;
-                                bool occluded;
-                                if (A.shadow_lds) {
-                                    float closest = tmax_s; uint32_t best = 0U;
-                                    closest_hit_runs<true, true>(T, sruns, SD.n_sruns, sh_slots, p, sd, F3(rcp_fast(sd.x), rcp_fast(sd.y), rcp_fast(sd.z)), 0.01f, 0.01f, closest, best, SD.srun_pack[0], SD.srun_pack[1]);
-                                    occluded = best != 0U;
-                                } else occluded = fastshadow::any_hit(S, p, sd, 0.01f, tmax_s);
-                                if (occluded) intensity -= per;
-                            }
-                        }
-                        if (skip) continue;   // 01: an occluded light is skipped entirely
-                        float dd = fmaxf(0.0f, strict::dot(tod, n));
-                        float sdot = fmaxf(0.0f, strict::dot(strict::reflect(-tod, n), -d));
-                        float sp = powf(sdot, m1.y);
-                        diffuse = madd(F3(l1), dd * intensity, diffuse);
-                        specular = madd(F3(l1), sp * intensity, specular);
-                    }
-                    f3 primary = diffuse * F3(m0) + specular * m1.x;                                     // :446
-                    acc = madd(primary, weight * (1.0f - wp), acc);
-                }
-                if (p2s < 1.0f) {                                                                        // :450-481
-                    bool do_refl = r2r > 0.0f, do_refr = r2r < 1.0f;
-                    float w_refl = weight * wp * (1.0f - wr), w_refr = weight * wp * wr;
-                    f3 d_refl = strict::normalize(strict::reflect(d, n)), d_refr = d;
-                    if (do_refr) {                                                                       // :467-475
-                        float eta = m2.x;
-                        f3 nn = n;
-                        if (strict::dot(n, -d) < 0.0f) { nn = -n; eta = 1.0f / eta; }
-                        d_refr = strict::normalize(strict::refract(d, nn, eta));
-                    }
-                    int cd = depth + 1;
-                    if (do_refl && do_refr) {   // park the refraction child in the slot of its depth
-                        stk[cd][0][tid] = p.x; stk[cd][1][tid] = p.y; stk[cd][2][tid] = p.z;
-                        stk[cd][3][tid] = d_refr.x; stk[cd][4][tid] = d_refr.y; stk[cd][5][tid] = d_refr.z;
-                        stk[cd][6][tid] = w_refr; stk[cd][7][tid] = __uint_as_float(node * 2U + 1U);
-                        pending |= 1U << cd;
-                    }
-                    if (do_refl || do_refr) {
-                        o = p; tmin = 0.001f; depth = cd;
-                        if (do_refl) { d = d_refl; weight = w_refl; node = node * 2U; }
-                        else         { d = d_refr; weight = w_refr; node = node * 2U + 1U; }
-                        done_node = false;
-                    }
-                }
-            }
-            if (done_node) {
-                if (pending == 0U) active = false;
-                else {
-                    int k = 31 - __clz((int)pending);
-                    pending &= ~(1U << k);
-                    o = F3(stk[k][0][tid], stk[k][1][tid], stk[k][2][tid]);
-                    d = F3(stk[k][3][tid], stk[k][4][tid], stk[k][5][tid]);
-                    weight = stk[k][6][tid]; node = __float_as_uint(stk[k][7][tid]);
-                    depth = k; tmin = 0.001f;
-                }
-            }
-        }
-    }
-    if (inside) out[pixel] = make_float4(acc.x, acc.y, acc.z, 1.0f);
-    wave_add_u64(counters + 2 * (blockIdx.x % RT_COUNTER_BANKS), rays);
-    wave_add_u64(counters + 2 * (blockIdx.x % RT_COUNTER_BANKS) + 1, srays);
+    whitted_body<SOFT>(SD, A, out, counters);
 }
 
-void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st) {
+void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 7) / 8));
     WhittedArgs B = A;
     // the stack only ever holds the refraction child of a hit that ALSO reflects (0 < reflectToRefract < 1 on a material with
     // primaryToSecondary < 1): none of the reference's scenes has one, and then no LDS is spent on it (more blocks per CU)
     B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : 0;
     B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed;
+    if (soft && jit) {   // scene-specialised whitted_body<true>: its shadow samples need no staged slots
+        B.shadow_lds = 0;
+        DevScene s = S;
+        void* params[] = {&s, &B, &out, &counters};
+        (void)hipModuleLaunchKernel(jit, grid.x, 1, 1, WBLOCK, 1, 1, (unsigned)B.stack_bytes, st, params, nullptr);
+        return;
+    }
     size_t lds = (size_t)B.stack_bytes + (B.shadow_lds ? (size_t)S.slot_bytes + 256 : 0);   // + one slot of slack for the read-ahead of wide slots
     if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
     else      hipLaunchKernelGGL(k_whitted<false>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);

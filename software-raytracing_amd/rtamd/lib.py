@@ -47,6 +47,7 @@ def load():
         L.rt_debug_set_regen_threshold.argtypes = [C.c_void_p, C.c_int32]
         L.rt_debug_set_flags.argtypes = [C.c_void_p, C.c_int32]
         L.rt_debug_last_path_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        L.rt_debug_last_whitted_kernel.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -126,6 +127,10 @@ class Context:
         buf = C.create_string_buffer(2048)
         kind = self.L.rt_debug_last_path_kernel(self.h, buf, 2048)
         return kind, buf.value.decode(errors="replace")
+
+    def last_whitted_kernel(self):
+        """2 scene-specialised (02 only), 1 generic"""
+        return self.L.rt_debug_last_whitted_kernel(self.h)
 
     def set_debug_flags(self, f):
         self._chk(self.L.rt_debug_set_flags(self.h, f))

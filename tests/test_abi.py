@@ -81,6 +81,12 @@ def test_scene_specialised_kernel_source_compiles_for_every_primitive_type():
     big = scenes.scene_stress(n_spheres=80, grid=2, spp=1)[0]
     note = C.create_string_buffer(1024); sc = big.c()
     assert L.rt_debug_jit_probe(C.byref(sc), 4, note, 1024) == 0 and b"specialised up to 64" in note.value
+    # the 02 kernel (variant 2): its shadow samples use the same generated query
+    s2 = scenes.scene02(16)[0]
+    s2.triangle(0, (-1, 0, -4), (1, 0, -4), (0, 1, -4))
+    sc = s2.c(); note = C.create_string_buffer(8192)
+    rc = L.rt_debug_jit_probe(C.byref(sc), 2, note, 8192)
+    assert rc in (0, 1) and b"compile failed" not in note.value and b"hiprtcCreateProgram" not in note.value, note.value.decode()
 
 
 def test_bvh_builder_covers_every_bounded_slot_exactly_once():

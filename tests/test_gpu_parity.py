@@ -258,6 +258,32 @@ def test_specialisation_policy_and_cache_across_scenes(ctx):
     assert not np.array_equal(imgs["a"], imgs["b"])
 
 
+def test_02_scene_specialised_kernel_matches_generic(ctx):
+    """02's shadow samples (16 of its 17 rays per pixel) run generated code for small scenes, like the path kernels'
+    scene query (rt_jit.hip): same arithmetic, so the same image bit for bit and the same ray counts; 01 never specialises."""
+    s, cam, prm = scenes.scene02(16, seed=3)
+    ctx.set_debug_flags(8)
+    try:
+        a = ctx.render_whitted(s, cam, prm, 392, 280)
+        assert ctx.last_whitted_kernel() == 1
+        ctx.set_debug_flags(16)
+        b = ctx.render_whitted(s, cam, prm, 392, 280)
+        assert ctx.last_whitted_kernel() == 2, ctx.last_path_kernel()[1]
+    finally:
+        ctx.set_debug_flags(0)
+    assert (a["rays"], a["shadow_rays"]) == (b["rays"], b["shadow_rays"]) and a["shadow_rays"] == 16 * a["rays"]
+    assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["bgra"], b["bgra"])
+    c = ctx.render_whitted(s, cam, prm, 392, 280)            # default policy: this scene has been seen before
+    assert ctx.last_whitted_kernel() == 2 and np.array_equal(a["rgb"], c["rgb"])
+    s1, cam1, prm1 = scenes.scene01()
+    ctx.set_debug_flags(16)
+    try:
+        ctx.render_whitted(s1, cam1, prm1, 196, 140)
+        assert ctx.last_whitted_kernel() == 1
+    finally:
+        ctx.set_debug_flags(0)
+
+
 def test_lds_and_global_scene_paths_agree(ctx):
     """The same small scene through the LDS-staged kernel and (debug flag) the global-memory kernel: identical images."""
     s, cam, prm = scenes.scene04(8, seed=5)
