@@ -122,6 +122,26 @@ struct HostScene {
 
 float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 
+// Ray::intersectsTriangle (Common/Ray.hpp:150-212) precomputed: n = normalize(cross(e2, e1)) (:159) and rows 0, 1 of the
+// inverse of the matrix with COLUMNS e2, e1, n (:190, Math.hpp:635-654).  det == 0: Inverse returns zeros, which passes
+// (0,0) in the reference; 'degenerate' lets the callers keep such a triangle out instead.
+struct TriBasis { float n[3], r0[3], r1[3]; bool degenerate; };
+TriBasis tri_basis(const float* f) {
+    TriBasis T{};
+    float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
+    float n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};
+    float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    for (float& v : n) v = len > 0 ? v / len : 0.0f;
+    float m[9] = {e2[0], e1[0], n[0], e2[1], e1[1], n[1], e2[2], e1[2], n[2]};
+    float det = m[0] * m[4] * m[8] + m[1] * m[5] * m[6] + m[2] * m[3] * m[7] - m[2] * m[4] * m[6] - m[0] * m[5] * m[7] - m[1] * m[3] * m[8];
+    float di = det != 0 ? 1 / det : 0.0f;
+    float r0[3] = {(m[4] * m[8] - m[7] * m[5]) * di, (m[2] * m[7] - m[1] * m[8]) * di, (m[1] * m[5] - m[2] * m[4]) * di};
+    float r1[3] = {(m[5] * m[6] - m[3] * m[8]) * di, (m[0] * m[8] - m[2] * m[6]) * di, (m[3] * m[2] - m[0] * m[5]) * di};
+    for (int k = 0; k < 3; ++k) { T.n[k] = n[k]; T.r0[k] = r0[k]; T.r1[k] = r1[k]; }
+    T.degenerate = det == 0;
+    return T;
+}
+
 // Validates rt_scene and builds the device layout documented in rt_device.h.
 int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/, HostScene& H) {
     if (!s || s->n_prims < 0 || s->n_materials < 0 || s->n_lights < 0) return fail(c, RT_ERR_BAD_ARG, "scene: null or negative count");
@@ -193,20 +213,12 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
                 wide = true;
                 break; }
             case RT_PRIM_TRIANGLE: {
-                float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
-                float n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};   // cross(e2,e1), Ray.hpp:159
-                float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                for (float& v : n) v = len > 0 ? v / len : 0.0f;
-                // Inverse of the matrix with COLUMNS e2, e1, n (Ray.hpp:190, Math.hpp:635-654); rows 0 and 1 are needed
-                float m[9] = {e2[0], e1[0], n[0], e2[1], e1[1], n[1], e2[2], e1[2], n[2]};
-                float det = m[0] * m[4] * m[8] + m[1] * m[5] * m[6] + m[2] * m[3] * m[7] - m[2] * m[4] * m[6] - m[0] * m[5] * m[7] - m[1] * m[3] * m[8];
-                float di = det != 0 ? 1 / det : 0.0f;
-                float r0[3] = {(m[4] * m[8] - m[7] * m[5]) * di, (m[2] * m[7] - m[1] * m[8]) * di, (m[1] * m[5] - m[2] * m[4]) * di};
-                float r1[3] = {(m[5] * m[6] - m[3] * m[8]) * di, (m[0] * m[8] - m[2] * m[6]) * di, (m[3] * m[2] - m[0] * m[5]) * di};
+                const TriBasis T = tri_basis(f);
+                const float *n = T.n, *r0 = T.r0, *r1 = T.r1;
                 G = f4(n[0], n[1], n[2], n[0] * f[0] + n[1] * f[1] + n[2] * f[2]);
                 G1 = f4(r0[0], r0[1], r0[2], -(r0[0] * f[0] + r0[1] * f[1] + r0[2] * f[2]));
                 G2 = f4(r1[0], r1[1], r1[2], -(r1[0] * f[0] + r1[1] * f[1] + r1[2] * f[2]));
-                if (det == 0) G1 = f4(0, 0, 0, -1.0f);   // degenerate: Inverse returns zeros and (0,0) passes in the reference; keep it out here
+                if (T.degenerate) G1 = f4(0, 0, 0, -1.0f);
                 B = f4(n[0], n[1], n[2], 0); C = B;
                 wide = true;
                 break; }
@@ -257,19 +269,10 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         case RT_PRIM_SPHERE: H.geom.push_back(f4(f[0], f[1], f[2], f[3])); break;
         case RT_PRIM_PLANE: H.geom.push_back(f4(f[3], f[4], f[5], 0)); H.geom.push_back(f4(f[0], f[1], f[2], 0)); break;   // n, p0
         case RT_PRIM_TRIANGLE: {
-            float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
-            float n[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};   // cross(e2,e1), Ray.hpp:159
-            float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-            for (float& v : n) v = len > 0 ? v / len : 0.0f;
-            // Inverse of the matrix with COLUMNS e2, e1, n (Ray.hpp:190, Math.hpp:635-654); rows 0 and 1 are needed
-            float m[9] = {e2[0], e1[0], n[0], e2[1], e1[1], n[1], e2[2], e1[2], n[2]};
-            float det = m[0] * m[4] * m[8] + m[1] * m[5] * m[6] + m[2] * m[3] * m[7] - m[2] * m[4] * m[6] - m[0] * m[5] * m[7] - m[1] * m[3] * m[8];
-            float di = det != 0 ? 1 / det : 0.0f;
-            float r0[3] = {(m[4] * m[8] - m[7] * m[5]) * di, (m[2] * m[7] - m[1] * m[8]) * di, (m[1] * m[5] - m[2] * m[4]) * di};
-            float r1[3] = {(m[5] * m[6] - m[3] * m[8]) * di, (m[0] * m[8] - m[2] * m[6]) * di, (m[3] * m[2] - m[0] * m[5]) * di};
-            if (det == 0) { r0[0] = r0[1] = r0[2] = -1.0f; }   // degenerate: Inverse returns zeros, (0,0) passes in the reference; keep it out here
-            H.geom.push_back(f4(n[0], n[1], n[2], n[0] * f[0] + n[1] * f[1] + n[2] * f[2]));
-            H.geom.push_back(f4(f[0], f[1], f[2], 0)); H.geom.push_back(f4(r0[0], r0[1], r0[2], 0)); H.geom.push_back(f4(r1[0], r1[1], r1[2], 0));
+            TriBasis T = tri_basis(f);
+            if (T.degenerate) T.r0[0] = T.r0[1] = T.r0[2] = -1.0f;
+            H.geom.push_back(f4(T.n[0], T.n[1], T.n[2], T.n[0] * f[0] + T.n[1] * f[1] + T.n[2] * f[2]));
+            H.geom.push_back(f4(f[0], f[1], f[2], 0)); H.geom.push_back(f4(T.r0[0], T.r0[1], T.r0[2], 0)); H.geom.push_back(f4(T.r1[0], T.r1[1], T.r1[2], 0));
             break; }
         default: return fail(c, RT_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": unknown type " + std::to_string(P.type));
         }
@@ -636,6 +639,8 @@ int32_t rt_debug_bvh_probe(const rt_scene* scene, int32_t variant, int32_t* out)
     auto inside = [](const float4& lo, const float4& hi, const float* ilo, const float* ihi) {
         return lo.x <= ilo[0] && lo.y <= ilo[1] && lo.z <= ilo[2] && hi.x >= ihi[0] && hi.y >= ihi[1] && hi.z >= ihi[2]; };
     std::vector<int> visits(n_nodes, 0);
+    std::vector<const BvhItem*> item_of(H.slots.size() / 4 + 1, nullptr);      // by slot offset / 64
+    for (const BvhItem& it : H.items) item_of[(it.ref & ~63U) / 64] = &it;
     for (int k = 0; k < n_nodes; ++k) {
         for (int ch = 0; ch < 2; ++ch) {
             const float4 lo = B.nodes[4 * k + 2 * ch], hi = B.nodes[4 * k + 2 * ch + 1];
@@ -655,8 +660,8 @@ int32_t rt_debug_bvh_probe(const rt_scene* scene, int32_t variant, int32_t* out)
                 for (uint32_t i = 0; i < n; ++i) {
                     const uint32_t r = B.refs[first + i];
                     seen[(r & ~63U) / 64]++;
-                    for (const BvhItem& it : H.items)      // the unpadded box of the slot must lie inside the leaf's
-                        if (it.ref == r && !inside(lo, hi, it.lo, it.hi)) ++bad;
+                    const BvhItem* it = item_of[(r & ~63U) / 64];      // the unpadded box of the slot must lie inside the leaf's
+                    if (!it || it->ref != r || !inside(lo, hi, it->lo, it->hi)) ++bad;
                 }
             }
         }

@@ -28,8 +28,8 @@ static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int
     if (jit && bytes <= RT_LDS_SCENE_MAX_BYTES) {   // scene-specialised k_path<VARIANT, true> (rt_jit.hip)
         DevScene s = S; PathArgs a = A;
         void* params[] = {&s, &a, &out, &counters};
-        (void)hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)bytes, st, params, nullptr);
-        return;
+        if (hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)bytes, st, params, nullptr) == hipSuccess) return;
+        (void)hipGetLastError();   // could not launch the specialised kernel: the generic one below renders the same image
     }
     if (A.debug_flags & 2)                   hipLaunchKernelGGL((k_path<VARIANT, false>), grid, dim3(256), 0, st, S, A, out, counters);   // A/B reference: scalar loads from the global blob
     else if (bytes <= RT_LDS_SCENE_MAX_BYTES) hipLaunchKernelGGL((k_path<VARIANT, true>), grid, dim3(256), bytes, st, S, A, out, counters);  // small scene: LDS-resident
@@ -86,11 +86,11 @@ void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* 
     B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : 0;
     B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed;
     if (soft && jit) {   // scene-specialised whitted_body<true>: its shadow samples need no staged slots
-        B.shadow_lds = 0;
+        WhittedArgs J = B; J.shadow_lds = 0;
         DevScene s = S;
-        void* params[] = {&s, &B, &out, &counters};
-        (void)hipModuleLaunchKernel(jit, grid.x, 1, 1, WBLOCK, 1, 1, (unsigned)B.stack_bytes, st, params, nullptr);
-        return;
+        void* params[] = {&s, &J, &out, &counters};
+        if (hipModuleLaunchKernel(jit, grid.x, 1, 1, WBLOCK, 1, 1, (unsigned)J.stack_bytes, st, params, nullptr) == hipSuccess) return;
+        (void)hipGetLastError();   // could not launch it: the generic kernel below renders the same image
     }
     size_t lds = (size_t)B.stack_bytes + (B.shadow_lds ? (size_t)S.slot_bytes + 256 : 0);   // + one slot of slack for the read-ahead of wide slots
     if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
