@@ -109,6 +109,25 @@ struct HostScene {
             } else if (dtype == PRIM_TRI && tri) {
                 for (int a = 0; a < 3; ++a) { it.lo[a] = std::min(tri[a], std::min(tri[3 + a], tri[6 + a])); it.hi[a] = std::max(tri[a], std::max(tri[3 + a], tri[6 + a])); }
             } else it.bounded = false;       // planes
+            if (n_f4 == 8) {
+                // wide slots carry a bounding sphere (centre, R^2) in their last float4: k_path_tiled skips a rectangle / triangle
+                // whose sphere no lane of the wave can hit.  Padded like the BVH boxes (rounding of p = o + t*d and of the inclusive
+                // edge tests); a primitive without finite bounds gets an infinite sphere (never skipped).
+                float c[3] = {0, 0, 0}, r2 = INFINITY;
+                bool ok = true;
+                for (int a = 0; a < 3; ++a) ok = ok && std::isfinite(it.lo[a]) && std::isfinite(it.hi[a]);
+                if (ok && it.bounded) {
+                    float m = 0.0f, h2 = 0.0f;
+                    for (int a = 0; a < 3; ++a) {
+                        c[a] = 0.5f * (it.lo[a] + it.hi[a]);
+                        const float h = 0.5f * (it.hi[a] - it.lo[a]); h2 += h * h;      // the box's half diagonal bounds every corner / vertex
+                        m = std::max(m, std::max(std::fabs(it.lo[a]), std::fabs(it.hi[a])));
+                    }
+                    const float r = sqrtf(h2) * 1.0001f + 1e-3f + 1e-4f * m;
+                    r2 = r * r;
+                }
+                slots[slots.size() - 1] = make_float4(c[0], c[1], c[2], r2);
+            }
             for (int a = 0; a < 3; ++a) if (!std::isfinite(it.lo[a]) || !std::isfinite(it.hi[a])) it.bounded = false;
             items.push_back(it);
         }

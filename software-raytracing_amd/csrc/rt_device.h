@@ -121,7 +121,7 @@ __device__ __forceinline__ void rng_pair(uint32_t skey, uint32_t ctr, float& a, 
 // The path kernels (03/04) read a second section of the blob, 'slots': the primitives IN SCENE ORDER (order
 // matters: exact ties and the sphere tMax rule depend on it), each a fixed number of float4 per device type,
 //   [G | A | B | C]            sphere, plane, axis-aligned plane      (4 float4 = 64 bytes)
-//   [G | A | B | C | G1 G2 G3 -] rectangle, triangle                   (8 float4 = 128 bytes)
+//   [G | A | B | C | G1 G2 G3 S] rectangle, triangle                   (8 float4 = 128 bytes); S = bounding sphere (centre, R^2)
 // G..G3 feed the ray test, A,B,C feed shading and sit at the same offsets for every type, so the closest-hit
 // loop only has to remember WHERE the winner is (its byte offset in the blob), not what it is:
 //   A = (c.xyz, k)   B = (m.xyz, byte offset of the material record)   C = (f.xyz, 0)
@@ -137,7 +137,7 @@ __device__ __forceinline__ void rng_pair(uint32_t skey, uint32_t ctr, float& a, 
 // even when the slots are staged in LDS: they steer uniform control flow, which wants SGPRs, while primitive
 // operands want VGPRs (an SGPR operand halves VALU issue rate on gfx950, profiles/r01_valu_issue_rates_ubench.txt).
 #define RT_TILE_BYTES 16384   /* k_path_tiled stages the slot section through LDS in pieces of at most this size */
-enum { SLOT_BYTES = 64, SLOT_A = 16, SLOT_B = 32, SLOT_C = 48, SLOT_G1 = 64, SLOT_G2 = 80, SLOT_G3 = 96 };
+enum { SLOT_BYTES = 64, SLOT_A = 16, SLOT_B = 32, SLOT_C = 48, SLOT_G1 = 64, SLOT_G2 = 80, SLOT_G3 = 96, SLOT_BOUND = 112 };
 
 // Scene memory: either the global blob (base pointer + byte offset; uniform offsets become scalar loads) or its LDS
 // copy, where an "offset" IS the 32-bit LDS address (the staging base is folded in once, not added per read).
@@ -167,7 +167,10 @@ template <bool LDS> struct SceneMem {
 // All traced directions are unit vectors (Ray's constructor normalises), so a = d.d = 1 in the sphere test.
 // PACKED: the run descriptors come from two 64-bit kernel-argument words (16 bits each: type | count << 3, at most 8 runs)
 // instead of scalar loads: no memory latency per run, which matters where few waves are resident (k_whitted).
-template <bool LDS, bool PACKED = false>
+// EARLY (scenes of thousands of primitives, k_path_tiled): a wave skips the rest of a test that none of its lanes can pass -
+// a sphere whose discriminant is negative in every lane (its roots would be NaN and fail every compare), a rectangle or
+// triangle whose (padded) bounding sphere the ray's line misses in every lane.  Exact, and with small primitives the common case.
+template <bool LDS, bool PACKED = false, bool EARLY = false>
 __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
                                                  f3 o, f3 d, f3 inv_d, float tmin, float tminp, float& closest, uint32_t& best,
                                                  unsigned long long pack0 = 0ULL, unsigned long long pack1 = 0ULL) {
@@ -194,7 +197,9 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
                 f3 co = F3(g) - o;
                 float b = dot(d, co);
                 float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, -g.w)));
-                float s = sqrt_fast(fmaf(b, b, -c));
+                float disc = fmaf(b, b, -c);
+                if (EARLY && __builtin_amdgcn_ballot_w64(disc >= 0.0f) == 0ULL) continue;
+                float s = sqrt_fast(disc);
                 float t1 = b - s, t2 = b + s;
                 bool near_behind = t1 < tmin;
                 float tc = near_behind ? t2 : t1;
@@ -227,6 +232,13 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
             // coordinates at the hit point p = o + t*d with the constant offset folded into the row's w.
             const bool rect = type == PRIM_RECT;
             for (int i = 0; i < count; ++i, q += 2 * SLOT_BYTES) {
+                if (EARLY) {   // the line of the ray against the slot's bounding sphere; the slack covers the rounding of the discriminant (~1e-6 |co|^2)
+                    float4 bs = M.ld4(q + SLOT_BOUND);
+                    f3 co = F3(bs) - o;
+                    float b = dot(d, co), cc = dot(co, co);
+                    float disc = fmaf(b, b, bs.w - cc);
+                    if (__builtin_amdgcn_ballot_w64(fmaf(cc, 4e-6f, disc) >= 0.0f) == 0ULL) continue;
+                }
                 float4 g = M.ld4(q), g1 = M.ld4(q + SLOT_G1), g2 = M.ld4(q + SLOT_G2);
                 float t = (g.w - dot(F3(g), o)) * rcp_fast(dot(F3(g), d));
                 f3 p = madd(d, t, o);
@@ -243,12 +255,12 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
 }
 // The whole scene in one go: q = SceneMem address of the first slot.  Returns the address of the winning slot (0 = miss:
 // address 0 is the runs section, or the first bytes of LDS, never a slot) and its distance.
-template <bool LDS>
+template <bool LDS, bool EARLY = false>
 __device__ __forceinline__ uint32_t closest_hit_slots(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
                                                       f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {
     uint32_t best = 0U;
     float closest = tmax;
-    closest_hit_runs<LDS>(M, runs, n_runs, q, o, d, F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)), tmin, tminp, closest, best);
+    closest_hit_runs<LDS, false, EARLY>(M, runs, n_runs, q, o, d, F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)), tmin, tminp, closest, best);
     t_out = closest;
     return best;
 }

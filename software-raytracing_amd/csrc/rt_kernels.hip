@@ -12,9 +12,9 @@ namespace rt {
 // =================================================================================================
 // K3/K4: path tracing (device code in rt_path_device.h).
 // =================================================================================================
-template <int VARIANT, bool LDS>
+template <int VARIANT, bool LDS, bool EARLY = false>
 __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
-    path_body<VARIANT, LDS>(SD, A, out, counters);
+    path_body<VARIANT, LDS, EARLY>(SD, A, out, counters);
 }
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_path_tiled(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
@@ -32,6 +32,8 @@ static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int
         (void)hipGetLastError();   // could not launch the specialised kernel: the generic one below renders the same image
     }
     if (A.debug_flags & 2)                   hipLaunchKernelGGL((k_path<VARIANT, false>), grid, dim3(256), 0, st, S, A, out, counters);   // A/B reference: scalar loads from the global blob
+    else if (bytes <= RT_LDS_SCENE_MAX_BYTES && S.slot_bytes > 64 * 64)   // mid-size scene (beyond the specialised builds): LDS-resident, wave-level early-outs
+        hipLaunchKernelGGL((k_path<VARIANT, true, true>), grid, dim3(256), bytes, st, S, A, out, counters);
     else if (bytes <= RT_LDS_SCENE_MAX_BYTES) hipLaunchKernelGGL((k_path<VARIANT, true>), grid, dim3(256), bytes, st, S, A, out, counters);  // small scene: LDS-resident
     else                                     hipLaunchKernelGGL((k_path_tiled<VARIANT>), grid, dim3(256), RT_TILE_BYTES, st, S, A, out, counters);   // large scene: LDS-tiled
 }

@@ -151,7 +151,8 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
 
 // Small scenes (blob <= 48 KB, LDS = true): every block stages the whole blob in LDS once.  LDS = false: the blob is
 // read from global memory with scalar loads (debug flag 2; A/B reference for the other two kernels).
-template <int VARIANT, bool LDS>
+// EARLY: wave-level early-outs in the primitive tests (rt_device.h), for scenes of many small primitives.
+template <int VARIANT, bool LDS, bool EARLY = false>
 __device__ __forceinline__ void path_body(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 smem[];
     const char* base = reinterpret_cast<const char*>(SD.blob);
@@ -186,7 +187,7 @@ __device__ __forceinline__ void path_body(const DevScene& SD, const PathArgs& A,
             const uint32_t hit = k ? k + (slots0 - SLOT_BYTES) : 0U;
             (void)runs;
 #else
-            uint32_t hit = closest_hit_slots<LDS>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+            uint32_t hit = closest_hit_slots<LDS, EARLY>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
 #endif
             shade<VARIANT, LDS>(M, A, mats0, hit, t, L);
         }
@@ -237,7 +238,7 @@ __device__ __forceinline__ void path_tiled_body(const DevScene& SD, const PathAr
             __syncthreads();
             if (L.alive) {
                 uint32_t b = 0U;
-                closest_hit_runs<true>(T, runs + ch.z, ch.w, tile0, L.o, L.d, inv_d, A.t_min, A.t_min_pos, closest, b);
+                closest_hit_runs<true, false, true>(T, runs + ch.z, ch.w, tile0, L.o, L.d, inv_d, A.t_min, A.t_min_pos, closest, b);
                 if (b) best = b - tile0 + (uint32_t)ch.x;
             }
         }
