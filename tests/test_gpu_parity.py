@@ -207,6 +207,25 @@ def test_stress_scene_reduced_tiled_kernel(ctx):
         assert abs(g["rays"] - o["rays"]) <= max(2, 2e-2 * o["rays"]) and g["samples"] == w * h * 4
 
 
+def test_mid_size_scene_lds_resident_with_early_outs(ctx):
+    """184 primitives: too many for a scene-specialised build, small enough to stay in LDS: k_path<., true, EARLY> whose
+    waves leave a primitive test early when no lane can pass it.  Exact: bit-identical to the plain global-memory kernel
+    (no early-outs), and the same paths as the oracle."""
+    s, cam, prm = scenes.scene_stress(n_spheres=150, grid=4, spp=8, seed=7)
+    assert len(s.prims) == 150 + 1 + 32 + 1
+    g = ctx.render_path(s, cam, prm, 160, 90)
+    assert ctx.last_path_kernel()[0] == 1
+    ctx.set_debug_flags(2)
+    try:
+        b = ctx.render_path(s, cam, prm, 160, 90)
+    finally:
+        ctx.set_debug_flags(0)
+    assert g["rays"] == b["rays"] and np.array_equal(g["rgb"], b["rgb"])
+    o = oracle.render_path(s, cam, prm, 160, 90, threads=8)
+    assert abs(g["rays"] - o["rays"]) <= 5e-3 * o["rays"]
+    assert frac_within(g["rgb"], o["sum"] / 8, 1e-3) >= 0.97
+
+
 @pytest.mark.parametrize("which", ["04", "03", "mixed"])
 def test_scene_specialised_kernel_matches_generic(ctx, which):
     """Small scenes run a kernel whose scene query was generated for that scene (hiprtc, rt_jit.hip): same arithmetic
