@@ -192,21 +192,37 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
             // Ray::intersectsSphere (Common/Ray.hpp:94-137).  Roots t1 <= t2; "a root below tMin becomes tMax" (:127-128):
             // a ray that starts inside a sphere whose far root lies beyond tMax still reports a hit AT tMax (:129-134):
             // the element wins, the distance stays.  disc < 0 gives NaN roots, which fail every compare.
-            for (int i = 0; i < count; ++i, q += SLOT_BYTES) {
-                float4 g = M.ld4(q);
-                f3 co = F3(g) - o;
-                float b = dot(d, co);
-                float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, -g.w)));
-                float disc = fmaf(b, b, -c);
-                if (EARLY && __builtin_amdgcn_ballot_w64(disc >= 0.0f) == 0ULL) continue;
-                float s = sqrt_fast(disc);
-                float t1 = b - s, t2 = b + s;
-                bool near_behind = t1 < tmin;
-                float tc = near_behind ? t2 : t1;
-                bool ge = tc >= tmin, le = tc <= closest;
-                closest = (ge & le) ? tc : closest;
-                best = (ge & (near_behind | le)) ? q : best;
+#define RT_SPHERE_DISC(G, B, DISC) f3 co_ = F3(G) - o; B = dot(d, co_); \
+                DISC = fmaf(B, B, -fmaf(co_.z, co_.z, fmaf(co_.y, co_.y, fmaf(co_.x, co_.x, -(G).w))))
+#define RT_SPHERE_ROOTS(B, DISC, Q) { float s = sqrt_fast(DISC); float t1 = (B) - s, t2 = (B) + s; \
+                bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; bool ge = tc >= tmin, le = tc <= closest; \
+                closest = (ge & le) ? tc : closest; best = (ge & (near_behind | le)) ? (Q) : best; }
+            int i = 0;
+            if (EARLY) {   // four spheres per early-out decision: a quarter of the branches, independent discriminants overlap
+                for (; i + 3 < count; i += 4, q += 4 * SLOT_BYTES) {
+                    float4 g0 = M.ld4(q), g1 = M.ld4(q + SLOT_BYTES), g2 = M.ld4(q + 2 * SLOT_BYTES), g3 = M.ld4(q + 3 * SLOT_BYTES);
+                    float b0, d0, b1, d1, b2, d2, b3, d3;
+                    { RT_SPHERE_DISC(g0, b0, d0); }
+                    { RT_SPHERE_DISC(g1, b1, d1); }
+                    { RT_SPHERE_DISC(g2, b2, d2); }
+                    { RT_SPHERE_DISC(g3, b3, d3); }
+                    // fmaxf drops NaNs: all four negative (or NaN) <=> the maximum is negative (or NaN): one compare for the four
+                    if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)) >= 0.0f) == 0ULL) continue;
+                    RT_SPHERE_ROOTS(b0, d0, q)
+                    RT_SPHERE_ROOTS(b1, d1, q + SLOT_BYTES)
+                    RT_SPHERE_ROOTS(b2, d2, q + 2 * SLOT_BYTES)
+                    RT_SPHERE_ROOTS(b3, d3, q + 3 * SLOT_BYTES)
+                }
             }
+            for (; i < count; ++i, q += SLOT_BYTES) {
+                float4 g = M.ld4(q);
+                float b, disc;
+                { RT_SPHERE_DISC(g, b, disc); }
+                if (EARLY && __builtin_amdgcn_ballot_w64(disc >= 0.0f) == 0ULL) continue;
+                RT_SPHERE_ROOTS(b, disc, q)
+            }
+#undef RT_SPHERE_DISC
+#undef RT_SPHERE_ROOTS
         } else if (type >= PRIM_AAPLANE_X) {
             // Ray::intersectsPlane (Ray.hpp:223-249) for a normal +-e_axis: n.p0 - n.o = +-(p0_a - o_a), d.n = +-d_a, so
             // t = (p0_a - o_a) * (1/d_a), 1/d shared by all such planes of the ray.  tminp = max(tMin, smallest positive
