@@ -414,6 +414,10 @@ def test_error_paths(ctx):
     with pytest.raises(lib.RtError) as e:
         ctx.render_whitted(s1, cam1, prm1, 8, 8)
     assert e.value.code == abi.RT_ERR_TOO_LARGE
+    for opt, val in ((abi.RT_OPT_ACCEL, 7), (99, 0)):            # unknown option value / unknown option
+        with pytest.raises(lib.RtError) as e:
+            ctx.set_option(opt, val)
+        assert e.value.code == abi.RT_ERR_BAD_ARG
     # the context still works after errors
     s, cam, prm = scenes.scene04(2)
     assert ctx.render_path(s, cam, prm, 16, 16)["samples"] == 512

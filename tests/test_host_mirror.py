@@ -189,3 +189,15 @@ def test_progressive_checkpointed_render_equals_one_shot(tmp_path):
     # a checkpoint of another frame is refused
     bad = subprocess.run(base[:-2] + ["--seed", "4", "--chunk", "10", "--checkpoint", ck], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 1 and "is not a checkpoint of this frame" in bad.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("example", [3, 4])
+def test_example_bvh_flag_gives_the_same_frame(example, tmp_path):
+    """example03/04 --bvh (rt_set_option(RT_OPT_ACCEL, RT_ACCEL_BVH) through the host mirror): byte-identical PPM."""
+    exe = _need(os.path.join(BIN, f"example0{example}"))
+    base = [exe, "--width", "160", "--height", "120", "--samples", "8", "--seed", "5"]
+    a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    subprocess.run(base + ["--out", a], check=True, capture_output=True, timeout=120)
+    subprocess.run(base + ["--bvh", "--out", b], check=True, capture_output=True, timeout=120)
+    assert open(a, "rb").read() == open(b, "rb").read()
