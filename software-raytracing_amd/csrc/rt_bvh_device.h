@@ -118,9 +118,10 @@ __device__ __forceinline__ uint32_t closest_hit_bvh(const DevScene& SD, const Sc
     return H.best;
 }
 
-// The bounce loop of path_body with the tree walk as its scene query; the scene is read from global memory (per-lane addresses).
+// The bounce loop of path_body with the tree walk as its scene query (one ray per lane, the walk as a function); the scene is
+// read from global memory (per-lane addresses).  Kept under debug flag 32 as the A/B reference of the scheduled form below.
 template <int VARIANT>
-__device__ __forceinline__ void path_bvh_body(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+__device__ __forceinline__ void path_bvh_body_simple(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     extern __shared__ uint32_t stack_mem[];       // (tree depth) x 256 entries
     uint32_t* stack = stack_mem + threadIdx.x;
     const SceneMem<false> M{reinterpret_cast<const char*>(SD.blob)};
@@ -142,6 +143,112 @@ __device__ __forceinline__ void path_bvh_body(const DevScene& SD, const PathArgs
             float t;
             uint32_t hit = closest_hit_bvh(SD, M, stack, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
             shade<VARIANT, false>(M, A, 0U, hit, t, L);
+        }
+    }
+    if (inside) out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);
+    wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
+}
+
+
+// ---- k_path_bvh, scheduled form -----------------------------------------------------------------------------------------
+// With one ray per lane and the walk as a function (path_bvh_body_simple below), a wave spends most of its time waiting for
+// its slowest lane: a ray needs 22 inner steps and 2.6 leaves on average on the stress scene, the slowest of 64 several times
+// that.  Here a lane is a small state machine - START (ray ready, walk not begun), TRAV (holds an inner node), LEAF (holds a
+// leaf), SHADE (walk finished), IDLE (path ended) - and the wave runs a STAGE when enough lanes wait for it: several rounds of
+// inner steps per iteration, leaves and shading when a quarter of the wave has queued up for them or nothing else can run,
+// regeneration likewise.  A lane never waits for another lane's walk, only for company in its next stage.  Per lane the
+// sequence of operations - and so every bit of the result - is that of the simple form.
+enum { BVH_IDLE = 0, BVH_START = 1, BVH_TRAV = 2, BVH_LEAF = 3, BVH_SHADE = 4 };
+#define RT_BVH_INNER_ROUNDS 8
+#define RT_BVH_QUORUM 48
+
+template <int VARIANT>
+__device__ __forceinline__ void path_bvh_body(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    extern __shared__ uint32_t stack_mem[];       // (tree depth) x 256 entries
+    uint32_t* stack = stack_mem + threadIdx.x;
+    const SceneMem<false> M{reinterpret_cast<const char*>(SD.blob)};
+    const float4* __restrict__ nodes = SD.blob + SD.off_bvh_nodes;
+    const uint32_t* __restrict__ refs = reinterpret_cast<const uint32_t*>(SD.blob + SD.off_bvh_refs);
+    const uint32_t* __restrict__ unb = reinterpret_cast<const uint32_t*>(SD.blob + SD.off_bvh_unbounded);
+    int px, py;
+    bool inside = pixel_of_thread(A.width, A.height, px, py);
+    const int slice = blockIdx.y;
+    int s_first = A.sample_begin + slice * A.slice_len;
+    const int s_end = min(s_first + A.slice_len, A.sample_end);
+    if (!inside) s_first = s_end;
+    const uint32_t pixel = (uint32_t)(py * A.width + px);
+    const uint32_t pkey = rng_pixel_key(A.seed, pixel);
+    PathLane L = lane_init(s_first);
+    int state = BVH_IDLE, sp = 0, budget = 0;
+    uint32_t cur = 0U;
+    BvhHit H; H.closest = 0.0f; H.best = 0U; H.steal = 0U; H.steal_t = 0.0f;
+    f3 inv_d = F3(0, 0, 0);
+
+    for (;;) {
+        const bool want = state == BVH_IDLE && L.s_next < s_end;
+        const unsigned long long m_want = __builtin_amdgcn_ballot_w64(want);
+        const int n_trav = __popcll(__builtin_amdgcn_ballot_w64(state == BVH_TRAV || state == BVH_START));
+        const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(state == BVH_LEAF));
+        const int n_shade = __popcll(__builtin_amdgcn_ballot_w64(state == BVH_SHADE));
+        const int n_want = __popcll(m_want);
+        if (n_trav + n_leaf + n_shade + n_want == 0) break;
+
+        // regeneration: idle lanes take the next sample of their pixel
+        if (n_want > 0 && (n_want >= RT_BVH_QUORUM || n_trav + n_leaf + n_shade < RT_BVH_QUORUM)) {
+            regenerate(A, px, py, pkey, want, m_want, 0ULL, L);
+            if (want) state = BVH_START;
+        }
+        // inner steps (a ray that is ready first tests the planes and takes the root)
+        for (int round = 0; round < RT_BVH_INNER_ROUNDS; ++round) {
+            if (__builtin_amdgcn_ballot_w64(state == BVH_TRAV || state == BVH_START) == 0ULL) break;
+            if (state == BVH_START) {
+                ++L.rays;
+                H.closest = A.t_max; H.best = 0U; H.steal = 0U; H.steal_t = 0.0f;
+                inv_d = F3(rcp_fast(L.d.x), rcp_fast(L.d.y), rcp_fast(L.d.z));
+                for (int i = 0; i < SD.n_bvh_unbounded; ++i) bvh_test(M, unb[i], L.o, L.d, inv_d, A.t_min, A.t_min_pos, H);
+                sp = 0; cur = 0U; budget = 2 * SD.n_bvh_nodes + 2;
+                state = SD.n_bvh_refs > 0 ? BVH_TRAV : BVH_SHADE;
+            } else if (state == BVH_TRAV) {
+                const float4* __restrict__ nd = nodes + 4U * cur;
+                const float4 l0 = nd[0], l1 = nd[1], r0 = nd[2], r1 = nd[3];
+                const uint32_t rl = __float_as_uint(l0.w), rr = __float_as_uint(l1.w);
+                float tl, tr;
+                const bool hl = bvh_box(l0, l1, L.o, inv_d, H.closest, tl), hr = bvh_box(r0, r1, L.o, inv_d, H.closest, tr);
+                if (hl & hr & (sp < SD.bvh_depth)) {
+                    const bool left_first = tl <= tr;
+                    stack[sp * 256] = left_first ? rr : rl; ++sp;
+                    cur = left_first ? rl : rr;
+                } else if (hl | hr) cur = hl ? rl : rr;
+                else if (sp == 0) cur = RT_BVH_NONE;
+                else { --sp; cur = stack[sp * 256]; }
+                if (cur == RT_BVH_NONE || --budget <= 0) state = BVH_SHADE;      // (the budget only matters for a malformed tree)
+                else if (cur & 0x80000000U) state = BVH_LEAF;
+            }
+        }
+        // leaves
+        {
+            const int nl = __popcll(__builtin_amdgcn_ballot_w64(state == BVH_LEAF));
+            const int nt = __popcll(__builtin_amdgcn_ballot_w64(state == BVH_TRAV || state == BVH_START));
+            if (nl > 0 && (nl >= RT_BVH_QUORUM || nt < RT_BVH_QUORUM)) {
+                if (state == BVH_LEAF) {
+                    const uint32_t first = (cur & 0x7fffffffU) >> 3, n = (cur & 7U) + 1U;
+                    for (uint32_t i = 0; i < n; ++i) bvh_test(M, refs[first + i], L.o, L.d, inv_d, A.t_min, A.t_min_pos, H);
+                    if (sp == 0) state = BVH_SHADE;
+                    else { --sp; cur = stack[sp * 256]; state = (cur & 0x80000000U) ? BVH_LEAF : BVH_TRAV; }
+                }
+            }
+        }
+        // shading
+        {
+            const int ns = __popcll(__builtin_amdgcn_ballot_w64(state == BVH_SHADE));
+            const int nb = __popcll(__builtin_amdgcn_ballot_w64(state == BVH_TRAV || state == BVH_START || state == BVH_LEAF));
+            if (ns > 0 && (ns >= RT_BVH_QUORUM || nb < RT_BVH_QUORUM)) {
+                if (state == BVH_SHADE) {
+                    if ((H.steal > H.best) & (H.steal_t > H.closest)) H.best = H.steal;
+                    shade<VARIANT, false>(M, A, 0U, H.best, H.closest, L);
+                    state = L.alive ? BVH_START : BVH_IDLE;
+                }
+            }
         }
     }
     if (inside) out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);

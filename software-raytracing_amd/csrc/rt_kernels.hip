@@ -43,16 +43,18 @@ void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out,
 }
 
 // Optional BVH walk (rt_set_option(RT_OPT_ACCEL, RT_ACCEL_BVH)): same bounce loop, the scene query walks a tree.
-template <int VARIANT>
+template <int VARIANT, bool SIMPLE>
 __global__ __launch_bounds__(256) void k_path_bvh(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
-    path_bvh_body<VARIANT>(SD, A, out, counters);
+    if (SIMPLE) path_bvh_body_simple<VARIANT>(SD, A, out, counters);
+    else        path_bvh_body<VARIANT>(SD, A, out, counters);
 }
 void launch_path_bvh(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 15) / 16), n_slices);
     // the walk is bound by the latency of dependent fetches, so resident waves matter: the per-lane stack takes only what this tree needs
     const size_t lds = (size_t)(S.bvh_depth > 0 ? S.bvh_depth : 1) * 256 * sizeof(uint32_t);
-    if (variant == 3) hipLaunchKernelGGL((k_path_bvh<3>), grid, dim3(256), lds, st, S, A, out, counters);
-    else              hipLaunchKernelGGL((k_path_bvh<4>), grid, dim3(256), lds, st, S, A, out, counters);
+    const bool simple = A.debug_flags & 32;     // one walk per lane as a function (A/B reference of the scheduled form)
+    if (variant == 3) { if (simple) hipLaunchKernelGGL((k_path_bvh<3, true>), grid, dim3(256), lds, st, S, A, out, counters); else hipLaunchKernelGGL((k_path_bvh<3, false>), grid, dim3(256), lds, st, S, A, out, counters); }
+    else              { if (simple) hipLaunchKernelGGL((k_path_bvh<4, true>), grid, dim3(256), lds, st, S, A, out, counters); else hipLaunchKernelGGL((k_path_bvh<4, false>), grid, dim3(256), lds, st, S, A, out, counters); }
 }
 
 // Sum the per-slice partial images in a fixed order (deterministic), out = float4(sum rgb, samples).
