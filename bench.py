@@ -75,10 +75,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to time")
+    # BENCH_REHEARSAL=1: rehearse the N > 1 code path on a box with ONE GPU - every rank on device 0, gloo instead of RCCL
+    # (RCCL refuses two ranks on one device).  The numbers of such a run mean nothing; the driver never sets it.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     W, H, SPP = args.width, args.height, args.spp
     ctx = lib.Context(local)
@@ -146,7 +154,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"04_PathTracingLights scene (5 planes, 3 spheres, 1 emissive rectangle), {W}x{H}, {SPP} spp, max depth 6, seed 1",
                        "samples_per_step": W * H * SPP, "rays_per_step": rays_step, "samples_per_sec": W * H * SPP * args.steps / dt,
-                       "parallelism": f"sample-range x{world}, one all-reduce(sum) of the {W * H * 16 / 1e6:.1f} MB accumulator" if world > 1 else "single GPU"},
+                       "parallelism": (f"sample-range x{world}, one all-reduce(sum) of the {W * H * 16 / 1e6:.1f} MB accumulator" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")) if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": traffic, "kernel": {2: "k_path_jit (scene-specialised rt::path_body<4, true>, hiprtc)", 1: "rt::k_path<4, true>", 0: "rt::k_path_tiled<4>"}.get(ctx.last_path_kernel()[0], "?"), "kernel_ms": k_ms, "flops_per_ray": fpr, "rays_per_launch": rays,
                          "note": "FP32 VALU-bound path (no MFMA, negligible HBM traffic): algorithmic FLOPs/ray x rays / kernel time vs the FP32 vector peak"},
