@@ -98,3 +98,19 @@ def test_bvh_full_stress_scene_is_far_faster_than_brute_force(ctx):
     a, b = _both(ctx, s, cam, prm, 320, 180)
     _same(a, b)
     assert b["kernel_ms"] * 8 < a["kernel_ms"], (a["kernel_ms"], b["kernel_ms"])
+
+
+def test_bvh_scheduled_walk_matches_the_function_form(ctx):
+    """k_path_bvh schedules stages over a per-lane state machine (rt_bvh_device.h); debug flag 32 runs the plain form (one
+    walk per lane as a function).  Per lane the operations are the same, so the frames are bit-identical."""
+    s, cam, prm = scenes.scene_stress(n_spheres=900, grid=16, spp=6, seed=13)
+    ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_BVH)
+    try:
+        a = ctx.render_path(s, cam, prm, 200, 120)
+        ctx.set_debug_flags(32)
+        b = ctx.render_path(s, cam, prm, 200, 120)
+    finally:
+        ctx.set_debug_flags(0)
+        ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_NONE)
+    _same(a, b)
+    assert a["rays"] > 200 * 120 * 6
