@@ -34,45 +34,6 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-} // namespace
-
-struct rt_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timing_pending = false;
-    DevBuf scene_buf, partial, accum, bgra, rgb;
-    unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
-    unsigned long long* h_counters = nullptr;     // pinned
-    std::string jit_note;                         // why the last path render was not scene-specialised ("" = it was)
-    int last_path_kernel = -1;                    // 3 BVH walk, 2 specialised, 1 generic LDS-resident, 0 tiled / global
-    int last_whitted_kernel = -1;                 // 2 specialised (02 only), 1 generic
-    void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned scene staging
-    uint64_t pending_samples = 0;
-    rt_stats stats{};
-    std::string err;
-    int regen_threshold_override = -1;
-    int debug_flags = 0;
-    int accel = 0;                                // RT_OPT_ACCEL: 0 brute force (the reference's algorithm), 1 BVH
-};
-
-namespace {
-
-int fail(rt_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
-#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-
-// math::GetRotationMat (Common/Math.hpp:913-930): Euler degrees -> 3x3, row-major out[9].
-void rotation_mat(const float deg[3], float out[9]) {
-    const double k = 3.14159265358979323846 / 180.0f;
-    float ax = (float)(deg[0] * k), ay = (float)(deg[1] * k), az = (float)(deg[2] * k);
-    float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
-    // columns i, j, k of the reference constructor; storage is row-major (Math.hpp:401-406)
-    float i[3] = {cz * cy, sz * cy, -sy};
-    float j[3] = {cz * sy * sx - sz * cx, sz * sy * sx + cz * cx, cy * sx};
-    float kk[3] = {cz * sy * cx + sz * sx, sz * sy * cx - cz * sx, cy * cx};
-    for (int r = 0; r < 3; ++r) { out[3 * r] = i[r]; out[3 * r + 1] = j[r]; out[3 * r + 2] = kk[r]; }
-}
-
 struct HostScene {
     std::vector<int4> runs, info;         // Whitted scenes: the IEEE-exact layout of rt_strict.h
     std::vector<int4> sruns;              // slot layout: runs over 'slots' (all path queries; 02's shadow samples)
@@ -138,6 +99,48 @@ struct HostScene {
         chunks.back().y += bytes;
     }
 };
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_pending = false;
+    DevBuf scene_buf, partial, accum, bgra, rgb;
+    unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
+    unsigned long long* h_counters = nullptr;     // pinned
+    std::string jit_note;                         // why the last path render was not scene-specialised ("" = it was)
+    int last_path_kernel = -1;                    // 3 BVH walk, 2 specialised, 1 generic LDS-resident, 0 tiled / global
+    int last_whitted_kernel = -1;                 // 2 specialised (02 only), 1 generic
+    void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned scene staging
+    uint64_t pending_samples = 0;
+    rt_stats stats{};
+    std::string err;
+    int regen_threshold_override = -1;
+    int debug_flags = 0;
+    int accel = 0;                                // RT_OPT_ACCEL: 0 brute force (the reference's algorithm), 1 BVH
+    // what scene_buf holds: a render of the same scene (same bytes, variant, BVH or not, stream) skips compile, build and upload
+    bool cache_valid = false; uint64_t cache_key = 0; hipStream_t cache_stream = nullptr;
+    HostScene cache_H; DevScene cache_D{};
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// math::GetRotationMat (Common/Math.hpp:913-930): Euler degrees -> 3x3, row-major out[9].
+void rotation_mat(const float deg[3], float out[9]) {
+    const double k = 3.14159265358979323846 / 180.0f;
+    float ax = (float)(deg[0] * k), ay = (float)(deg[1] * k), az = (float)(deg[2] * k);
+    float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
+    // columns i, j, k of the reference constructor; storage is row-major (Math.hpp:401-406)
+    float i[3] = {cz * cy, sz * cy, -sy};
+    float j[3] = {cz * sy * sx - sz * cx, sz * sy * sx + cz * cx, cy * sx};
+    float kk[3] = {cz * sy * cx + sz * sx, sz * sy * cx - cz * sx, cy * cx};
+    for (int r = 0; r < 3; ++r) { out[3 * r] = i[r]; out[3 * r + 1] = j[r]; out[3 * r + 2] = kk[r]; }
+}
 
 float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 
@@ -366,6 +369,45 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     return RT_OK;
 }
 
+// compile_scene + (optional) build_bvh + upload_scene behind a one-entry cache keyed by the scene's bytes: progressive and
+// repeated renders of one scene (the BVH build of the stress scene alone is 20 ms) pay for it once.
+uint64_t scene_key(const rt_scene* s, int variant, int accel) {
+    uint64_t h = 1469598103934665603ULL;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p; size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ULL; }
+        for (; i < n; ++i) h = (h ^ b[i]) * 1099511628211ULL;
+    };
+    const int32_t head[5] = {variant, accel, s->n_prims, s->n_materials, s->n_lights};
+    mix(head, sizeof head);
+    if (s->n_prims > 0 && s->prims) mix(s->prims, (size_t)s->n_prims * sizeof(rt_prim));
+    if (s->n_materials > 0 && s->materials) mix(s->materials, (size_t)s->n_materials * sizeof(rt_material));
+    if (s->n_lights > 0 && s->lights) mix(s->lights, (size_t)s->n_lights * sizeof(rt_light));
+    return h;
+}
+int prepare_scene(rt_ctx* c, const rt_scene* scene, int variant, bool accel, hipStream_t st, const HostScene*& H, DevScene& D) {
+    if (!scene || scene->n_prims < 0 || scene->n_materials < 0 || scene->n_lights < 0 || (scene->n_prims && !scene->prims) ||
+        (scene->n_materials && !scene->materials) || (scene->n_lights && !scene->lights)) {
+        HostScene tmp; return compile_scene(c, scene, variant, tmp);      // reports the error
+    }
+    const uint64_t key = scene_key(scene, variant, accel ? 1 : 0);
+    if (!(c->cache_valid && c->cache_key == key && c->cache_stream == st)) {
+        c->cache_valid = false;
+        c->cache_H = HostScene();
+        int rc = compile_scene(c, scene, variant, c->cache_H);
+        if (rc) return rc;
+        if (accel) {
+            build_bvh(c->cache_H.items, c->cache_H.bvh);
+            if (c->cache_H.bvh.depth > RT_BVH_STACK)
+                return fail(c, RT_ERR_TOO_LARGE, "BVH deeper than the traversal stack (" + std::to_string(c->cache_H.bvh.depth) + " > " + std::to_string(RT_BVH_STACK) + ")");
+        }
+        if ((rc = upload_scene(c, c->cache_H, st, c->cache_D))) return rc;
+        c->cache_key = key; c->cache_stream = st; c->cache_valid = true;
+    }
+    H = &c->cache_H; D = c->cache_D;
+    return RT_OK;
+}
+
 int begin_timed(rt_ctx* c, hipStream_t st) {
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
@@ -493,14 +535,10 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     if (s0 == 0 && s1 == 0) s1 = p->spp;
     if (p->spp <= 0 || s0 < 0 || s1 < s0 || p->max_depth < 0) return fail(c, RT_ERR_BAD_ARG, "bad spp / sample range / max_depth");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    HostScene H; DevScene D;
-    if ((rc = compile_scene(c, scene, p->variant, H))) return rc;
     const bool accel = c->accel == 1;
-    if (accel) {
-        build_bvh(H.items, H.bvh);
-        if (H.bvh.depth > RT_BVH_STACK) return fail(c, RT_ERR_TOO_LARGE, "BVH deeper than the traversal stack (" + std::to_string(H.bvh.depth) + " > " + std::to_string(RT_BVH_STACK) + ")");
-    }
-    if ((rc = upload_scene(c, H, st, D))) return rc;
+    const HostScene* Hp = nullptr; DevScene D;
+    if ((rc = prepare_scene(c, scene, p->variant, accel, st, Hp, D))) return rc;
+    const HostScene& H = *Hp;
 
     PathArgs A{};
     A.width = width; A.height = height; A.sample_begin = s0; A.sample_end = s1; A.max_depth = p->max_depth;
@@ -549,9 +587,9 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
     for (int k = 0; k < 3; ++k)
         if (cam->position[k] != 0.0f || cam->orientation_deg[k] != 0.0f) return fail(c, RT_ERR_BAD_ARG, "examples 01/02 have a fixed camera: position/orientation must be zero");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    HostScene H; DevScene D;
-    if ((rc = compile_scene(c, scene, 0, H))) return rc;
-    if ((rc = upload_scene(c, H, st, D))) return rc;
+    const HostScene* Hp = nullptr; DevScene D;
+    if ((rc = prepare_scene(c, scene, 0, false, st, Hp, D))) return rc;
+    const HostScene& H = *Hp;
     WhittedArgs A{};
     A.width = width; A.height = height; A.max_depth = p->max_depth; A.shadow_samples = p->shadow_samples; A.seed = p->seed;
     float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 01 Main.cpp:333

@@ -303,6 +303,35 @@ def test_02_scene_specialised_kernel_matches_generic(ctx):
         ctx.set_debug_flags(0)
 
 
+def test_scene_cache_follows_the_scene_bytes(ctx):
+    """The context keeps the compiled scene of the last render and reuses it when the next scene has the same bytes (and
+    variant, stream, BVH option); any change of a primitive or material must be seen."""
+    s, cam, prm = scenes.scene04(4, seed=8)
+    a = ctx.render_path(s, cam, prm, 96, 64)
+    b = ctx.render_path(s, cam, prm, 96, 64)                     # cache hit
+    assert np.array_equal(a["rgb"], b["rgb"]) and a["rays"] == b["rays"]
+    old = s.prims[-2].f[3]
+    s.prims[-2].f[3] = old * 1.5; s._c = None                    # a sphere's radius (scenes.Scene caches its ctypes arrays)
+    c = ctx.render_path(s, cam, prm, 96, 64)
+    assert not np.array_equal(a["rgb"], c["rgb"])
+    s.prims[-2].f[3] = old; s._c = None
+    d = ctx.render_path(s, cam, prm, 96, 64)
+    assert np.array_equal(a["rgb"], d["rgb"])
+    s.materials[0].albedo[0] *= 0.5; s._c = None                 # a material changes
+    e = ctx.render_path(s, cam, prm, 96, 64)
+    assert not np.array_equal(a["rgb"], e["rgb"])
+    ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_BVH)           # same bytes, other scene query: not a cache hit (the blob differs), same image
+    try:
+        f = ctx.render_path(s, cam, prm, 96, 64)
+    finally:
+        ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_NONE)
+    assert ctx.last_path_kernel()[0] == 3 and np.array_equal(e["rgb"], f["rgb"])
+    s2, cam2, prm2 = scenes.scene02(4)                           # a Whitted render in between replaces the cached scene
+    ctx.render_whitted(s2, cam2, prm2, 64, 48)
+    g = ctx.render_path(s, cam, prm, 96, 64)
+    assert np.array_equal(e["rgb"], g["rgb"])
+
+
 def test_lds_and_global_scene_paths_agree(ctx):
     """The same small scene through the LDS-staged kernel and (debug flag) the global-memory kernel: identical images."""
     s, cam, prm = scenes.scene04(8, seed=5)
