@@ -15,7 +15,7 @@
 
 namespace rt {
 
-#define RT_BVH_LEAF  4       /* primitives per leaf at most */
+#define RT_BVH_LEAF  2       /* primitives per leaf at most */
 
 struct BvhItem {
     float lo[3], hi[3];
