@@ -177,10 +177,11 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         switch (M.type) {
         case RT_MAT_PHONG: type = MAT_PHONG; break;
         case RT_MAT_DIFFUSE: type = MAT_DIFFUSE;
-            m2.y = (variant == 3) ? 90.0f / 57.2958f : cosf(90.0f / 57.2958f); break;                  // 03 Utils.h:82, 04 Utils.h:141
+            m2.y = (variant == 3) ? 90.0f / 57.2958f : cosf(90.0f / 57.2958f);                         // 03 Utils.h:82, 04 Utils.h:141
+            if (variant == 4) m2.x = (1.0f - m2.y) * (1.0f / 65536.0f); break;                          // the sampler's height = cone + (1 - cone)*u, u = k/65536
         case RT_MAT_METAL: type = MAT_METAL;
             if (variant == 3) m2.y = (M.roughness > 0.0f) ? (60.0f * M.roughness) / 57.2958f : -1.0f;   // 03 Materials.hpp:152-154
-            else m2.y = cosf((60.0f * M.roughness) / 57.2958f); break;                                   // 04 Metal.hpp:76
+            else { m2.y = cosf((60.0f * M.roughness) / 57.2958f); m2.x = (1.0f - m2.y) * (1.0f / 65536.0f); } break;   // 04 Metal.hpp:76
         case RT_MAT_DIELECTRIC: { type = MAT_DIELECTRIC;
             float ratio = 1.0f / M.refraction_index;                                                    // Schlick r0, 04 Refractive.hpp:24-25
             float r0 = (1.0f - ratio) / (1.0f + ratio);

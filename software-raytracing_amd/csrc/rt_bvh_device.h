@@ -142,7 +142,7 @@ __device__ __forceinline__ void path_bvh_body_simple(const DevScene& SD, const P
             ++L.rays;
             float t;
             uint32_t hit = closest_hit_bvh(SD, M, stack, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
-            shade<VARIANT, false>(M, A, 0U, hit, t, L);
+            shade<VARIANT, false>(M, A, 0U, hit == 0U, hit, t, L);
         }
     }
     if (inside) out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);
@@ -245,7 +245,7 @@ __device__ __forceinline__ void path_bvh_body(const DevScene& SD, const PathArgs
             if (ns > 0 && (ns >= RT_BVH_QUORUM || nb < RT_BVH_QUORUM)) {
                 if (state == BVH_SHADE) {
                     if ((H.steal > H.best) & (H.steal_t > H.closest)) H.best = H.steal;
-                    shade<VARIANT, false>(M, A, 0U, H.best, H.closest, L);
+                    shade<VARIANT, false>(M, A, 0U, H.best == 0U, H.best, H.closest, L);
                     state = L.alive ? BVH_START : BVH_IDLE;
                 }
             }

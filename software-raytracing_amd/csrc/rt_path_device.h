@@ -17,7 +17,7 @@ namespace rt {
 // Per-lane path state of the bounce loop.
 struct PathLane {
     f3 o, d, thr, acc;
-    uint32_t skey;
+    uint32_t skey, rkey;      // rkey = skey + (4*(depth+1) + 1)*0x9E3779B9: the argument of the bounce's draw, kept by adding instead of multiplying
     int depth, s_next, n_started;
     unsigned int rays;
     bool alive;
@@ -25,7 +25,7 @@ struct PathLane {
 __device__ __forceinline__ PathLane lane_init(int s_next) {
     PathLane L;
     L.o = F3(0, 0, 0); L.d = F3(0, 0, -1); L.thr = F3(0, 0, 0); L.acc = F3(0, 0, 0);
-    L.skey = 0; L.depth = 0; L.s_next = s_next; L.n_started = 0; L.rays = 0; L.alive = false;
+    L.skey = 0; L.rkey = 0; L.depth = 0; L.s_next = s_next; L.n_started = 0; L.rays = 0; L.alive = false;
     return L;
 }
 
@@ -34,12 +34,14 @@ __device__ __forceinline__ void regenerate(const PathArgs& A, int px, int py, ui
     if (m_want && (m_alive == 0ULL || __popcll(m_want) >= A.regen_threshold)) {
         if (want) {   // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369)
             L.skey = rng_sample_key(pkey, (uint32_t)L.s_next);
+            L.rkey = L.skey + 5U * 0x9E3779B9U;
             float bx = 0.5f, by = 0.5f;
             if (A.jitter) rng_pair(L.skey, 0U, bx, by);
             float x = fmaf((float)px + bx, A.inv_w2, -1.0f) * A.kx;
             float y = -fmaf((float)py + by, A.inv_h2, -1.0f) * A.ky;
             f3 v = F3(x, y, -1.0f);
-            L.d = normalize(F3(dot(F3(A.r[0], A.r[1], A.r[2]), v), dot(F3(A.r[3], A.r[4], A.r[5]), v), dot(F3(A.r[6], A.r[7], A.r[8]), v)));
+            const f3 rv = F3(dot(F3(A.r[0], A.r[1], A.r[2]), v), dot(F3(A.r[3], A.r[4], A.r[5]), v), dot(F3(A.r[6], A.r[7], A.r[8]), v));
+            L.d = rv * rsq_fast(dot(rv, rv));      // Normalize; |rv| >= 1 (v.z = -1, r a rotation), so its zero-vector guard cannot fire
             L.o = F3(A.px, A.py, A.pz);
             L.thr = F3(1, 1, 1);
             L.depth = 0;
@@ -54,10 +56,10 @@ __device__ __forceinline__ void regenerate(const PathArgs& A, int px, int py, ui
     const unsigned long long m_want = __builtin_amdgcn_ballot_w64(want), m_alive = __builtin_amdgcn_ballot_w64((L).alive)
 
 // One bounce after the scene query: miss / emit / scatter (TraceTay of 03 Main.cpp:392-435, 04 Main.cpp:447-502).
-// hit = SceneMem address of the winning slot (0 = miss), t = its distance.
+// hit = SceneMem address of the winning slot (unused when miss), t = its distance.
 template <int VARIANT, bool LDS>
-__device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, uint32_t mats0, uint32_t hit, float t, PathLane& L) {
-    if (hit == 0U) {
+__device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, uint32_t mats0, bool miss, uint32_t hit, float t, PathLane& L) {
+    if (miss) {
         if (VARIANT == 3) {   // sky: Mix(white, (0.5,0.7,1), 0.5*(d.y+1)) (03 Main.cpp:430-432)
             float h = 0.5f * (L.d.y + 1.0f);
             L.acc = L.acc + L.thr * F3(fmaf(-0.5f, h, 1.0f), fmaf(-0.3f, h, 1.0f), 1.0f);
@@ -74,16 +76,15 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
         f3 n = madd(pc, k, F3(sb));
         float facing = dot(L.d, madd(pc, k, F3(sc)));
         bool back = facing > 0.0f;
-        // n = back ? -n : n through the sign bit of (0 - facing): set exactly when facing > 0
-        uint32_t flip = __float_as_uint(0.0f - facing) & 0x80000000U;
-        n = F3(__uint_as_float(__float_as_uint(n.x) ^ flip), __uint_as_float(__float_as_uint(n.y) ^ flip), __uint_as_float(__float_as_uint(n.z) ^ flip));
+        n = sel(back, -n, n);      // face-forward (03 Sphere.hpp:69-73, 04 Scene/Sphere.hpp:70-74)
         const uint32_t moff = mats0 + __float_as_uint(sb.w);
         float4 m0 = M.ld4(moff), m2 = M.ld4(moff + 32U);
         int mtype = __float_as_int(m0.w);
         if (mtype == MAT_DIFFUSE || mtype == MAT_METAL || mtype == MAT_DIELECTRIC) {
             // one draw per bounce serves whichever material was hit: (fi, theta) halves for the hemisphere/cone
             // samplers, the top 24 bits for the dielectric's reflect-or-refract choice
-            const uint32_t r = rng_bits(L.skey, 4U * ((uint32_t)L.depth + 1U));
+            const uint32_t r = lowbias32(L.rkey);      // = rng_bits(L.skey, 4*(depth+1))
+            L.rkey += 4U * 0x9E3779B9U;
             const float dn = dot(L.d, n);
             const f3 refl = madd(n, -2.0f * dn, L.d);          // math::Reflect (Math.hpp:291-294)
             f3 nd;
@@ -102,7 +103,8 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
                 nd = axis;
                 if (m2.y >= 0.0f) {
                     // RndHemisphereVec (03 Utils.h:64-88) / RndHemisphereVec3 (04 Utils.h:132-157)
-                    float u_fi = (float)(r & 0xFFFFU) * (1.0f / 65536.0f), u_th = (float)(r >> 16) * (1.0f / 65536.0f);
+                    // the uniforms are k/65536; the power-of-two scale is folded into the constants they multiply (exact)
+                    const float k_fi = (float)(r & 0xFFFFU), k_th = (float)(r >> 16);
                     // b = Normalize(Cross(dir, dir + 0.01)) = Normalize(Cross(dir, (1,1,1))): the 0.01 and dir x dir cancel;
                     // c = Cross(dir, b) is already unit (dir, b orthonormal), so the reference's second Normalize is a no-op
                     f3 b = F3(axis.y - axis.z, axis.z - axis.x, axis.x - axis.y);
@@ -114,18 +116,18 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
                     // cos^2 + sin^2 = 1 to the last bit: v_sin/v_cos are each good to ~1e-5 only, and the sphere test
                     // amplifies an error in |L.d| by (distance/radius)^2
                     const float fi_rev = (float)((360.0 / 57.2958f) / 6.283185307179586);   // fi/(2*pi)
-                    float x_rev = u_fi * fi_rev;
+                    float x_rev = k_fi * (fi_rev * (1.0f / 65536.0f));
                     float cf = __builtin_amdgcn_cosf(x_rev);
                     float sf = sqrt_fast(fmaf(-cf, cf, 1.0f));
                     sf = __uint_as_float(__float_as_uint(sf) | (__float_as_uint(0.5f - x_rev) & 0x80000000U));   // negative beyond half a turn
                     float ct, st;
                     if (VARIANT == 3) {   // theta = U(-1,1)*thetaMax/57.2958
-                        float th_rev = (2.0f * u_th - 1.0f) * m2.y * 0.15915494309189535f;
+                        float th_rev = fmaf(k_th, 2.0f / 65536.0f, -1.0f) * m2.y * 0.15915494309189535f;
                         ct = __builtin_amdgcn_cosf(th_rev);
                         st = sqrt_fast(fmaf(-ct, ct, 1.0f));
                         st = __uint_as_float(__float_as_uint(st) | (__float_as_uint(th_rev) & 0x80000000U));      // |theta| <= 90 deg: sin has theta's sign
                     } else {              // theta = acos(U(cos(thetaMax/57.2958), 1))
-                        ct = fmaf(1.0f - m2.y, u_th, m2.y);
+                        ct = fmaf(m2.x, k_th, m2.y);      // m2.x = (1 - cone)/65536 (host-precomputed; exact power-of-two scaling)
                         st = sqrt_fast(fmaf(-ct, ct, 1.0f));   // ct <= 1 exactly (u_th < 1), so the fused 1 - ct*ct is never negative
                     }
                     nd = madd(madd(c, sf, b * cf), st, axis * ct);
@@ -184,12 +186,14 @@ __device__ __forceinline__ void path_body(const DevScene& SD, const PathArgs& A,
             float t;
 #ifdef RT_JIT_SCENE   // scene-specialised build (rt_jit.hip): the scene query is generated straight-line code
             const uint32_t k = closest_hit_jit(L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);   // slot offset + SLOT_BYTES, 0 = miss
-            const uint32_t hit = k ? k + (slots0 - SLOT_BYTES) : 0U;
+            const uint32_t hit = k + (slots0 - SLOT_BYTES);
+            const bool miss = k == 0U;
             (void)runs;
 #else
             uint32_t hit = closest_hit_slots<LDS, EARLY>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+            const bool miss = hit == 0U;
 #endif
-            shade<VARIANT, LDS>(M, A, mats0, hit, t, L);
+            shade<VARIANT, LDS>(M, A, mats0, miss, hit, t, L);
         }
     }
     if (inside) {
@@ -244,7 +248,7 @@ __device__ __forceinline__ void path_tiled_body(const DevScene& SD, const PathAr
         }
         if (L.alive) {
             ++L.rays;
-            shade<VARIANT, false>(G, A, 0U, best, closest, L);
+            shade<VARIANT, false>(G, A, 0U, best == 0U, best, closest, L);
         }
     }
     if (inside) out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);
