@@ -110,7 +110,9 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
                     f3 b = F3(axis.y - axis.z, axis.z - axis.x, axis.x - axis.y);
                     float bl2 = dot(b, b);
                     bool degenerate = !(bl2 > 0.0f);
-                    b = b * (degenerate ? 0.0f : rsq_fast(bl2));      // Normalize(0) = 0: the frame collapses for dir parallel to (1,1,1)
+                    // Normalize(0) = 0: the frame collapses for dir parallel to (1,1,1).  b is then exactly 0, so b * rsq(0 + 1e-30) = 0 too;
+                    // and a non-zero bl2 (>= ~1e-15: squares of differences of unit-vector components) is unchanged by adding 1e-30
+                    b = b * rsq_fast(bl2 + 1e-30f);
                     f3 c = cross(axis, b);
                     // fi = U*360/57.2958; cos from the hardware (input in revolutions), sin = +-sqrt(1 - cos^2) so that
                     // cos^2 + sin^2 = 1 to the last bit: v_sin/v_cos are each good to ~1e-5 only, and the sphere test
