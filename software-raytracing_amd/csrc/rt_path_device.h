@@ -53,7 +53,8 @@ __device__ __forceinline__ void regenerate(const PathArgs& A, int px, int py, ui
 // wave-level state of the bounce loop: which lanes are idle with samples left, which are tracing
 #define RT_WAVE_STATE(L, s_end) \
     const bool want = !(L).alive && (L).s_next < (s_end); \
-    const unsigned long long m_want = __builtin_amdgcn_ballot_w64(want), m_alive = __builtin_amdgcn_ballot_w64((L).alive)
+    const unsigned long long m_alive = __builtin_amdgcn_ballot_w64((L).alive), \
+                             m_want = ~m_alive & __builtin_amdgcn_ballot_w64((L).s_next < (s_end))   /* the compare's mask is fresh: no round trip through a VGPR */
 
 // One bounce after the scene query: miss / emit / scatter (TraceTay of 03 Main.cpp:392-435, 04 Main.cpp:447-502).
 // hit = SceneMem address of the winning slot (unused when miss), t = its distance.
