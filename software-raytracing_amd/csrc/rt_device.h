@@ -9,21 +9,20 @@
 namespace rt {
 
 // ---- flattened, precomputed scene (built on the host by compile_scene, rt_api.hip) -------------
-// One contiguous blob of float4 records; sections at float4 offsets off_*:
-// runs : one int4 per maximal run of same-type primitives, IN SCENE ORDER (order matters: ties
-//        and the sphere tMax rule depend on it) = {type, first geom float4 index, count, first prim index}
+// One contiguous blob of float4 records; sections at float4 offsets off_*.  Path scenes (03/04) and 02's shadow samples read
+// the SLOT section (see "slot layout" below); the sections described here serve the IEEE-exact Whitted tests of rt_strict.h:
+// runs : one int4 per maximal run of same-type primitives, IN SCENE ORDER (order matters: the first element wins ties
+//        in 01/02) = {type, first geom float4 index, count, first prim index}
 // geom : per-type records, float4 units (index relative to off_geom):
-//        sphere   1: (cx, cy, cz, r*r)               [Whitted scenes: (cx, cy, cz, r)]
-//        plane    1: (nx, ny, nz, n.p0)              [Whitted scenes: 2: (n, 0) (p0, 0), see rt_strict.h]
-//        aaplane  1: (p0[axis], n[axis] = +-1, 0, 0)  path scenes only: a plane whose unit normal is +-e_axis
-//        rect     5: (R00,R01,R02,px) (R10,R11,R12,py) (R20,R21,R22,pz) (hw,hh,nwx,nwy) (nwz,0,0,0)
-//                    R = GetRotationMat(-orientation), nw = GetRotationMat(orientation)*(0,0,1)
+//        sphere   1: (cx, cy, cz, r)
+//        plane    2: (n, 0) (p0, 0)
 //        triangle 4: (nx,ny,nz,n.v0) (v0x,v0y,v0z,0) (i00,i01,i02,0) (i10,i11,i12,0)
 //                    n = normalize(cross(e2,e1)), i = rows 0,1 of Inverse([e2 e1 n])
 // info : one int4 per primitive = {device type, geom index, material index, flags}
 // mats : 3 float4 per material:
 //        m0 (albedo.rgb, type as int bits)   m1 (specularIntensity, shininess, p2s, r2r)
-//        m2 (refractionEta, cone, refractionIndex, schlick r0)
+//        m2 (refractionEta [path variant 04: (1 - cone)/65536], cone, refractionIndex, schlick r0)
+//        m0.x of a dielectric: 1/refractionIndex
 //        cone: variant 04: cos(thetaMax/57.2958); variant 03: thetaMax/57.2958 (radians), <0 = no sampling
 // lights: 2 float4 per light: (pos.xyz, radius) (color.rgb, 0)
 struct DevScene {

@@ -1,5 +1,6 @@
-// rt_kernels.hip - the tracing kernels (gfx950).  One thread per pixel(-sample slice); scene
-// primitives are wave-uniform and come through scalar loads; no MFMA (FP32 VALU-bound path).
+// rt_kernels.hip - the tracing kernels (gfx950) and their launchers.  One thread per pixel(-sample slice); the device code
+// lives in rt_path_device.h, rt_whitted_device.h and rt_bvh_device.h (also embedded as text for the scene-specialised
+// hiprtc builds, rt_jit.hip).  No MFMA: the path is FP32 VALU-bound.
 #include "rt_device.h"
 #include "rt_strict.h"
 #include "rt_kernels.h"
