@@ -116,6 +116,13 @@ __device__ __forceinline__ void rng_pair(uint32_t skey, uint32_t ctr, float& a, 
     b = (float)(r >> 16) * (1.0f / 65536.0f);
 }
 
+// the two 16-bit halves of one draw as floats k (the uniforms are k/65536; callers fold the power-of-two scale into a constant)
+__device__ __forceinline__ void rng_pair_raw(uint32_t skey, uint32_t ctr, float& a, float& b) {
+    uint32_t r = lowbias32(skey + (ctr + 1U) * 0x9E3779B9U);
+    a = (float)(r & 0xFFFFU);
+    b = (float)(r >> 16);
+}
+
 // ---- path-tracing scenes: slot layout ---------------------------------------------------------------
 // The path kernels (03/04) read a second section of the blob, 'slots': the primitives IN SCENE ORDER (order
 // matters: exact ties and the sphere tMax rule depend on it), each a fixed number of float4 per device type,

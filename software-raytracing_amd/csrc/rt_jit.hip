@@ -80,7 +80,39 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
             q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
         }
     }
-    s += "    t_out = closest;\n    return best;\n}\n} // namespace rt\n";
+    s += "    t_out = closest;\n    return best;\n}\n";
+    // The same tests against a FIXED tMax, OR-ed (02's shadow samples): "something occludes" without the chain through
+    // 'closest'.  Equivalent to closest_hit_jit(...) != 0: a test that fails there only because an earlier element was closer
+    // changes nothing (that element occludes), and the sphere rule "origin inside, far root beyond tMax" occludes in both.
+    s += "__device__ __forceinline__ bool any_hit_jit(f3 o, f3 d, float tmin, float tminp, float tmax) {\n";
+    s += "    bool occ = false;\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d; (void)tmin; (void)tminp;\n";
+    q = 0;
+    for (const int4& run : sruns) {
+        for (int i = 0; i < run.z; ++i) {
+            const float4* g = &slots[q];
+            if (run.x == PRIM_SPHERE) {
+                s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
+                s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
+                s += "      float s = sqrt_fast(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;\n";
+                s += "      bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; occ |= (tc >= tmin) & (near_behind | (tc <= tmax)); }\n";
+            } else if (run.x >= PRIM_AAPLANE_X) {
+                const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
+                s += "    { float t = (" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + "; occ |= (t >= tminp) & (t <= tmax); }\n";
+            } else if (run.x == PRIM_PLANE) {
+                s += "    { float t = (" + lit(g[0].w) + " - dot(" + v3(g[0]) + ", o)) * rcp_fast(dot(" + v3(g[0]) + ", d)); occ |= (t >= tminp) & (t <= tmax); }\n";
+            } else {
+                const float4 &g1 = g[4], &g2 = g[5], &g3 = g[6];
+                s += "    { float t = (" + lit(g[0].w) + " - dot(" + v3(g[0]) + ", o)) * rcp_fast(dot(" + v3(g[0]) + ", d)); f3 p = madd(d, t, o);\n";
+                s += "      float x = fmaf(" + lit(g1.z) + ", p.z, fmaf(" + lit(g1.y) + ", p.y, fmaf(" + lit(g1.x) + ", p.x, " + lit(g1.w) + ")));\n";
+                s += "      float y = fmaf(" + lit(g2.z) + ", p.z, fmaf(" + lit(g2.y) + ", p.y, fmaf(" + lit(g2.x) + ", p.x, " + lit(g2.w) + ")));\n";
+                if (run.x == PRIM_RECT) s += "      bool in = (fabsf(x) <= " + lit(g3.x) + ") & (fabsf(y) <= " + lit(g3.y) + ");\n";
+                else                    s += "      bool in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);\n";
+                s += "      occ |= (t >= tminp) & (t <= tmax) & in; }\n";
+            }
+            q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
+        }
+    }
+    s += "    return occ;\n}\n} // namespace rt\n";
     return s;
 }
 

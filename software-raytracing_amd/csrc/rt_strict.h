@@ -175,6 +175,17 @@ static __device__ __forceinline__ bool any_hit(const Scn& S, f3 o, f3 d, float t
     }
     return hit;
 }
+// The same with the four uniforms given as their 16-bit integers k (u = k/65536) and radius_s = radius/65536: identical
+// results (scaling by a power of two is exact, so each product rounds the same real number), four multiplies fewer; and the
+// two Normalize zero guards become "+ 1e-30" on the squared length: a zero vector still maps to zero, and a non-zero squared
+// length here (>= ~1e-14) is the same float after adding 1e-30.
+static __device__ __forceinline__ f3 to_light_disk_raw(f3 p, f3 lp, f3 to, float radius_s, float k0, float k1, float k2, float k3) {
+    f3 vb = F3(fmaf(k0, 2.0f / 65536.0f, -1.0f), fmaf(k1, 2.0f / 65536.0f, -1.0f), fmaf(k2, 2.0f / 65536.0f, -1.0f));
+    f3 pl = cross(to, to + vb);
+    pl = pl * rsq_fast(dot(pl, pl) + 1e-30f);
+    f3 dir = madd(pl, radius_s * k3, lp) - p;
+    return dir * rsq_fast(dot(dir, dir) + 1e-30f);
+}
 // RandomVectorToLightSphere (02 Main.cpp:539-566); 'to' = normalize(lp - p) is the same for every sample of a light
 static __device__ __forceinline__ f3 to_light_disk(f3 p, f3 lp, f3 to, float radius, float u0, float u1, float u2, float u3) {
     f3 vb = F3(fmaf(2.0f, u0, -1.0f), fmaf(2.0f, u1, -1.0f), fmaf(2.0f, u2, -1.0f));

@@ -78,15 +78,16 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                         } else if (depth + 1 <= A.max_depth) {                                           // 02 :452-467, :539-566
                             float per = 1.0f / (float)A.shadow_samples;
                             float tmax_s = len - l0.w;
+                            const float radius_s = l0.w * (1.0f / 65536.0f);
                             for (int i = 0; i < A.shadow_samples; ++i) {
                                 uint32_t c = ((node * (uint32_t)S.n_lights + (uint32_t)li) * (uint32_t)A.shadow_samples + (uint32_t)i) * 4U;
-                                float u0, u1, u2, u3;
-                                rng_pair(skey, c, u0, u1); rng_pair(skey, c + 2U, u2, u3);
-                                f3 sd = fastshadow::to_light_disk(p, lp, tod, l0.w, u0, u1, u2, u3);
+                                float k0, k1, k2, k3;
+                                rng_pair_raw(skey, c, k0, k1); rng_pair_raw(skey, c + 2U, k2, k3);
+                                f3 sd = fastshadow::to_light_disk_raw(p, lp, tod, radius_s, k0, k1, k2, k3);
                                 ++srays;
                                 bool occluded;
 #ifdef RT_JIT_SCENE
-                                { float tt; occluded = closest_hit_jit(p, sd, 0.01f, 0.01f, tmax_s, tt) != 0U; }
+                                occluded = any_hit_jit(p, sd, 0.01f, 0.01f, tmax_s);
 #else
                                 if (A.shadow_lds) {
                                     float closest = tmax_s; uint32_t best = 0U;
