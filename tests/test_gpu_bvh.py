@@ -173,3 +173,19 @@ def test_random_scenes_every_kernel_agrees(ctx, seed, n):
         for name, f in frames.items():
             assert f["rays"] == ref["rays"], name
             assert np.array_equal(f["rgb"], ref["rgb"]), name
+
+
+@pytest.mark.parametrize("seed,n", [(21, 30), (22, 120), (23, 500)])
+def test_random_scenes_agree_with_the_oracle(ctx, seed, n):
+    """The same random scenes against the CPU oracle (same seeds, same counter-based draws): equal ray counts to 1 %, the
+    same paths on nearly every pixel (a path that grazes an edge differently diverges completely: chaotic, not a bias)."""
+    rng = np.random.default_rng(1000 + seed)
+    s = _random_scene(rng, n)
+    cam = scenes.camera(70.0, (0.3, 0.5, 6.0), (-3.0, 2.0, 1.0))
+    prm = scenes.path_params(abi.RT_PATH_LIGHTS, 4, max_depth=6, seed=seed)
+    g = ctx.render_path(s, cam, prm, 96, 72)
+    o = oracle.render_path(s, cam, prm, 96, 72, threads=8)
+    om = o["sum"] / 4
+    assert abs(g["rays"] - o["rays"]) <= 1e-2 * o["rays"]
+    assert np.mean(np.all(np.abs(g["rgb"] - om) <= 1e-3 * np.maximum(np.abs(om), 1e-3), axis=-1)) >= 0.95
+    assert np.allclose(g["rgb"].mean(axis=(0, 1)), om.mean(axis=(0, 1)), rtol=5e-2, atol=1e-3)
