@@ -21,6 +21,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))     # orc.py: the checker's binding
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (vector)"
 
@@ -29,7 +30,7 @@ def cpu_baseline(scenes, width, height, spp, rows, threads):
     """Times the oracle on `rows` rows in the middle of the same frame (same scene, camera, spp)."""
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
-    from rtamd import oracle
+    import orc as oracle
     s, cam, prm = scenes.scene04(spp, seed=1)
     L = oracle.lib()
     sc = s.c()
@@ -93,16 +94,27 @@ def main():
     s, cam, _ = scenes.scene04(SPP, seed=1)
     s_begin, s_end = shard.sample_range(rank, world, SPP)
     prm = scenes.path_params(abi.RT_PATH_LIGHTS, SPP, seed=1, sample_begin=s_begin, sample_end=s_end)
-    stream = torch.cuda.current_stream()
+    # A real side stream, made current for every step: the library's kernels are enqueued on ITS handle and torch orders the
+    # all-reduce (and RCCL's internal stream) against the same stream.  Torch's default stream has handle 0, which the
+    # library reads as "use my own non-blocking stream" - that stream is ordered against nothing torch does, so passing 0
+    # here would let RCCL reduce a half-written accumulator.
+    stream = torch.cuda.Stream()
     sp = stream.cuda_stream
+    assert sp != 0
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
     bgra = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    empty_share = shard.is_empty((s_begin, s_end))
 
     def step():
-        ctx.path_accumulate_device(s, cam, prm, W, H, accum.data_ptr(), sp)
-        if world > 1:
-            dist.all_reduce(accum, op=dist.ReduceOp.SUM)          # the one collective: per-GPU spp accumulators
-        ctx.resolve_device(accum.data_ptr(), W, H, float(SPP), 1, bgra.data_ptr(), 0, None, sp)
+        with torch.cuda.stream(stream):
+            if empty_share:
+                accum.zero_()                                        # spp < world: this rank adds nothing
+            else:
+                ctx.path_accumulate_device(s, cam, prm, W, H, accum.data_ptr(), sp)
+            if world > 1:
+                dist.all_reduce(accum, op=dist.ReduceOp.SUM)          # the one collective: per-GPU spp accumulators
+            ctx.resolve_device(accum.data_ptr(), W, H, float(SPP), 1, bgra.data_ptr(), 0, None, sp)
 
     def fence():
         if world > 1:
@@ -112,7 +124,7 @@ def main():
     # one-time setup, like loading the library: the library compiles a kernel specialised for this scene (hiprtc, ~0.7 s).  Its
     # default is to do that when it sees a scene for the second time; here it is asked to do it at the first render, which
     # is the first warmup step (with --warmup 0: a tiny 16x16 render, so that the compile is never inside the timed region)
-    ctx.set_debug_flags(16)
+    os.environ["RT_MI355_JIT"] = "2"          # the documented switch: specialise at the first render of a scene
     if args.warmup == 0:
         ctx.render_path(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, 1, seed=1), 16, 16)
     for _ in range(args.warmup):
@@ -133,6 +145,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
     dt = float(t.item()); rays_step = float(r.item())
+
+    if rehearsal and world > 1 and rank == 0:
+        # the composed frame (N sample-range shards + all-reduce + resolve) against the same frame rendered by one context alone
+        with torch.cuda.stream(stream):
+            solo_acc = torch.zeros_like(accum); solo = torch.zeros_like(bgra)
+            ctx.path_accumulate_device(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, SPP, seed=1), W, H, solo_acc.data_ptr(), sp)
+            ctx.resolve_device(solo_acc.data_ptr(), W, H, float(SPP), 1, solo.data_ptr(), 0, None, sp)
+        ctx.sync(sp)
+        diff = (solo.to(torch.int16) - bgra.to(torch.int16)).abs()
+        assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3, "rehearsal: composed frame differs from the single-context frame"
+        print(f"rehearsal: composed {world}-rank frame == single-context frame (max byte diff {int(diff.max())}, {float((diff > 0).float().mean()):.2e} of bytes differ)", file=sys.stderr)
 
     if rank == 0:
         fpr = scenes.flops_per_ray(s, 100)                           # 17*3 + 12*5 + 38 + 100 = 249

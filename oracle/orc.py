@@ -1,14 +1,18 @@
-"""ctypes wrapper of oracle/librt_oracle.so - the CPU restatement.  TEST INFRASTRUCTURE ONLY:
-imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product path."""
+"""orc - ctypes wrapper of oracle/librt_oracle.so, the CPU restatement.  TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product path (it lives outside the
+product package for that reason; it borrows the package's ctypes record definitions, rtamd.abi)."""
 import ctypes as C
 import os
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from . import abi
+import sys
 
-_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(_ROOT, "software-raytracing_amd"))
+from rtamd import abi  # noqa: E402
+
 _LIB = None
 
 

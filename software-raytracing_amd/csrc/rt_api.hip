@@ -106,6 +106,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_scene_use = nullptr;            // recorded behind the last work that reads scene_buf / h_stage, on whichever stream it ran
     bool timing_pending = false;
     DevBuf scene_buf, partial, accum, bgra, rgb;
     unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
@@ -122,6 +123,7 @@ struct rt_ctx {
     int accel = 0;                                // RT_OPT_ACCEL: 0 brute force (the reference's algorithm), 1 BVH
     // what scene_buf holds: a render of the same scene (same bytes, variant, BVH or not, stream) skips compile, build and upload
     bool cache_valid = false; uint64_t cache_key = 0; hipStream_t cache_stream = nullptr;
+    std::vector<unsigned char> cache_bytes;       // the rt_scene records the cache was built from: a hit is confirmed by comparing them, not by the hash alone
     HostScene cache_H; DevScene cache_D{};
 };
 
@@ -310,24 +312,29 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
     return RT_OK;
 }
 
-// Packs the HostScene into one pinned blob, uploads it and fills DevScene with device pointers.
-int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
+// Byte offsets of the sections of the scene blob (rt_device.h) for a HostScene.
+struct BlobLayout { size_t runs, sruns, chunks, geom, info, slots, mats, lights, bnodes, brefs, bunb, total; };
+BlobLayout blob_layout(const HostScene& H) {
     auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    BlobLayout L{};
     // one spare zero record after the runs: the path kernels prefetch runs[r + 1]
-    size_t o_runs = 0, o_sruns = pad(o_runs + (H.runs.size() + 1) * 16), o_chunks = pad(o_sruns + (H.sruns.size() + 1) * 16), o_geom = pad(o_chunks + H.chunks.size() * 16), o_info = pad(o_geom + H.geom.size() * 16),
-           o_slots = pad(o_info + (H.path ? 0 : H.info.size()) * 16), o_mats = pad(o_slots + H.slots.size() * 16),
-           o_lights = pad(o_mats + H.mats.size() * 16), o_bnodes = pad(o_lights + H.lights.size() * 16 + 16), o_brefs = pad(o_bnodes + H.bvh.nodes.size() * 16),
-           o_bunb = pad(o_brefs + H.bvh.refs.size() * 4), total = pad(o_bunb + H.bvh.unbounded.size() * 4 + 16);
-    if (total > c->h_stage_cap) {
-        if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
-        c->h_stage = nullptr; c->h_stage_cap = 0;
-        HIPCHK(c, hipHostMalloc(&c->h_stage, total * 2, hipHostMallocDefault));
-        c->h_stage_cap = total * 2;
-    }
-    HIPCHK(c, c->scene_buf.reserve(total));
-    // the staging blob may still be in flight from the previous call on this stream
-    HIPCHK(c, hipStreamSynchronize(st));
-    char* h = (char*)c->h_stage;
+    L.runs = 0; L.sruns = pad(L.runs + (H.runs.size() + 1) * 16); L.chunks = pad(L.sruns + (H.sruns.size() + 1) * 16);
+    L.geom = pad(L.chunks + H.chunks.size() * 16); L.info = pad(L.geom + H.geom.size() * 16);
+    L.slots = pad(L.info + (H.path ? 0 : H.info.size()) * 16); L.mats = pad(L.slots + H.slots.size() * 16);
+    L.lights = pad(L.mats + H.mats.size() * 16); L.bnodes = pad(L.lights + H.lights.size() * 16 + 16); L.brefs = pad(L.bnodes + H.bvh.nodes.size() * 16);
+    L.bunb = pad(L.brefs + H.bvh.refs.size() * 4); L.total = pad(L.bunb + H.bvh.unbounded.size() * 4 + 16);
+    return L;
+}
+
+// Packs the HostScene into the pinned staging buffer h (>= L.total bytes), copies it to the device blob d_blob (>= L.total
+// bytes) on st and fills DevScene.  'guard' is the event recorded behind the last work that read either buffer.
+int fill_and_upload_scene(rt_ctx* c, const HostScene& H, const BlobLayout& L, hipStream_t st, DevScene& D, char* h, void* d_blob, hipEvent_t guard) {
+    const size_t o_runs = L.runs, o_sruns = L.sruns, o_chunks = L.chunks, o_geom = L.geom, o_info = L.info, o_slots = L.slots, o_mats = L.mats,
+                 o_lights = L.lights, o_bnodes = L.bnodes, o_brefs = L.brefs, o_bunb = L.bunb, total = L.total;
+    if (o_slots == 0) return fail(c, RT_ERR_HIP, "internal: slot section at blob offset 0 (offset 0 means 'no hit')");
+    // the staging blob and the device blob may still be in use by the previous render - on this stream or on another one the
+    // caller passed then: wait for the event recorded behind that render's last kernel (valid even if its stream is gone)
+    HIPCHK(c, hipEventSynchronize(guard));
     memset(h, 0, o_geom);
     memcpy(h + o_runs, H.runs.data(), H.runs.size() * 16); memcpy(h + o_sruns, H.sruns.data(), H.sruns.size() * 16);
     for (size_t k = 0; k < H.chunks.size(); ++k) {   // slot-section offsets -> blob byte offsets
@@ -351,8 +358,8 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
         r = reinterpret_cast<uint32_t*>(h + o_bunb);
         for (size_t k = 0; k < H.bvh.unbounded.size(); ++k) r[k] = H.bvh.unbounded[k] + (uint32_t)o_slots;
     }
-    HIPCHK(c, hipMemcpyAsync(c->scene_buf.p, h, total, hipMemcpyHostToDevice, st));
-    D.blob = (const float4*)c->scene_buf.p;
+    HIPCHK(c, hipMemcpyAsync(d_blob, h, total, hipMemcpyHostToDevice, st));
+    D.blob = (const float4*)d_blob;
     D.off_runs = (int)(o_runs / 16); D.off_geom = (int)(o_geom / 16); D.off_info = (int)(o_info / 16);
     D.off_mats = (int)(o_mats / 16); D.off_lights = (int)(o_lights / 16); D.total_f4 = (int)(total / 16);
     D.n_runs = (int)H.runs.size(); D.n_prims = (int)H.info.size(); D.n_mats = (int)H.mats.size() / 3; D.n_lights = (int)H.lights.size() / 2;
@@ -368,6 +375,20 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
     D.off_bvh_nodes = (int)(o_bnodes / 16); D.off_bvh_refs = (int)(o_brefs / 16); D.off_bvh_unbounded = (int)(o_bunb / 16);
     D.n_bvh_refs = (int)H.bvh.refs.size(); D.n_bvh_unbounded = (int)H.bvh.unbounded.size(); D.bvh_depth = H.bvh.depth; D.n_bvh_nodes = (int)H.bvh.nodes.size() / 4;
     return RT_OK;
+}
+
+// The allocating form: grows the context's pinned staging buffer and device blob as needed.
+int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
+    const BlobLayout L = blob_layout(H);
+    if (L.total > c->h_stage_cap) {
+        HIPCHK(c, hipEventSynchronize(c->ev_scene_use));
+        if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+        c->h_stage = nullptr; c->h_stage_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_stage, L.total * 2, hipHostMallocDefault));
+        c->h_stage_cap = L.total * 2;
+    }
+    HIPCHK(c, c->scene_buf.reserve(L.total));
+    return fill_and_upload_scene(c, H, L, st, D, (char*)c->h_stage, c->scene_buf.p, c->ev_scene_use);
 }
 
 // compile_scene + (optional) build_bvh + upload_scene behind a one-entry cache keyed by the scene's bytes: progressive and
@@ -392,7 +413,13 @@ int prepare_scene(rt_ctx* c, const rt_scene* scene, int variant, bool accel, hip
         HostScene tmp; return compile_scene(c, scene, variant, tmp);      // reports the error
     }
     const uint64_t key = scene_key(scene, variant, accel ? 1 : 0);
-    if (!(c->cache_valid && c->cache_key == key && c->cache_stream == st)) {
+    const size_t nb_p = (size_t)scene->n_prims * sizeof(rt_prim), nb_m = (size_t)scene->n_materials * sizeof(rt_material), nb_l = (size_t)scene->n_lights * sizeof(rt_light);
+    bool hit = c->cache_valid && c->cache_key == key && c->cache_stream == st && c->cache_bytes.size() == nb_p + nb_m + nb_l;
+    if (hit) {   // a 64-bit hash can collide: the cached blob is only reused for the very same records
+        const unsigned char* b = c->cache_bytes.data();
+        hit = (!nb_p || !memcmp(b, scene->prims, nb_p)) && (!nb_m || !memcmp(b + nb_p, scene->materials, nb_m)) && (!nb_l || !memcmp(b + nb_p + nb_m, scene->lights, nb_l));
+    }
+    if (!hit) {
         c->cache_valid = false;
         c->cache_H = HostScene();
         int rc = compile_scene(c, scene, variant, c->cache_H);
@@ -403,20 +430,25 @@ int prepare_scene(rt_ctx* c, const rt_scene* scene, int variant, bool accel, hip
                 return fail(c, RT_ERR_TOO_LARGE, "BVH deeper than the traversal stack (" + std::to_string(c->cache_H.bvh.depth) + " > " + std::to_string(RT_BVH_STACK) + ")");
         }
         if ((rc = upload_scene(c, c->cache_H, st, c->cache_D))) return rc;
+        c->cache_bytes.resize(nb_p + nb_m + nb_l);
+        if (nb_p) memcpy(c->cache_bytes.data(), scene->prims, nb_p);
+        if (nb_m) memcpy(c->cache_bytes.data() + nb_p, scene->materials, nb_m);
+        if (nb_l) memcpy(c->cache_bytes.data() + nb_p + nb_m, scene->lights, nb_l);
         c->cache_key = key; c->cache_stream = st; c->cache_valid = true;
     }
     H = &c->cache_H; D = c->cache_D;
     return RT_OK;
 }
 
-int begin_timed(rt_ctx* c, hipStream_t st) {
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), st));
+int begin_timed(rt_ctx* c, hipStream_t st, unsigned long long* d_counters = nullptr) {
+    HIPCHK(c, hipMemsetAsync(d_counters ? d_counters : c->d_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
     return RT_OK;
 }
-int end_timed(rt_ctx* c, hipStream_t st) {
+int end_timed(rt_ctx* c, hipStream_t st, unsigned long long* d_counters = nullptr, hipEvent_t ev_use = nullptr) {
     HIPCHK(c, hipEventRecord(c->ev1, st));
-    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, RT_COUNTER_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(ev_use ? ev_use : c->ev_scene_use, st));     // the scene blob is free for rewriting once this has passed
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, d_counters ? d_counters : c->d_counters, RT_COUNTER_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     c->timing_pending = true;
     return RT_OK;
 }
@@ -459,7 +491,7 @@ rt_ctx* rt_create(int32_t device_id) {
     rt_ctx* c = new rt_ctx();
     c->device = dev;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
-              hipEventCreate(&c->ev1) == hipSuccess && hipMalloc((void**)&c->d_counters, RT_COUNTER_WORDS * sizeof(unsigned long long)) == hipSuccess &&
+              hipEventCreate(&c->ev1) == hipSuccess && hipEventCreateWithFlags(&c->ev_scene_use, hipEventDisableTiming) == hipSuccess && hipMalloc((void**)&c->d_counters, RT_COUNTER_WORDS * sizeof(unsigned long long)) == hipSuccess &&
               hipHostMalloc((void**)&c->h_counters, RT_COUNTER_WORDS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
     if (!ok) { g_create_error = "failed to create stream/events/counters"; rt_destroy(c); return nullptr; }
     memset(c->h_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long));
@@ -476,6 +508,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_scene_use) (void)hipEventDestroy(c->ev_scene_use);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -526,8 +559,8 @@ int32_t rt_sync(rt_ctx* c, void* stream) {
     return RT_OK;
 }
 
-int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p,
-                                  int32_t width, int32_t height, float* d_accum, void* stream) {
+static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p,
+                               int32_t width, int32_t height, float* d_accum, void* stream) {
     int rc = check_ctx(c); if (rc) return rc;
     if (!cam || !p || !d_accum || width <= 0 || height <= 0) return fail(c, RT_ERR_BAD_ARG, "rt_path_accumulate_device: null pointer or non-positive size");
     if ((long long)width * height > (1LL << 28)) return fail(c, RT_ERR_TOO_LARGE, "image larger than 2^28 pixels");
@@ -538,6 +571,7 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const bool accel = c->accel == 1;
     const HostScene* Hp = nullptr; DevScene D;
+    unsigned long long* counters = c->d_counters;
     if ((rc = prepare_scene(c, scene, p->variant, accel, st, Hp, D))) return rc;
     const HostScene& H = *Hp;
 
@@ -555,11 +589,13 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     A.px = cam->position[0]; A.py = cam->position[1]; A.pz = cam->position[2];
     int n_samples = s1 - s0;
     int slices = n_samples > 0 ? pick_slices(width, height, n_samples) : 1;
+    size_t npx = (size_t)width * height;
     A.slice_len = n_samples > 0 ? (n_samples + slices - 1) / slices : 1;
     slices = n_samples > 0 ? (n_samples + A.slice_len - 1) / A.slice_len : 1;
-    size_t npx = (size_t)width * height;
     float4* target = (float4*)d_accum;
-    if (slices > 1) { HIPCHK(c, c->partial.reserve(npx * slices * sizeof(float4))); target = (float4*)c->partial.p; }
+    float4* partial = nullptr;
+    if (slices > 1) { HIPCHK(c, c->partial.reserve(npx * slices * sizeof(float4))); partial = (float4*)c->partial.p; }
+    if (slices > 1) target = partial;
     // small scenes: the scene query compiled for THIS scene (literal operands, no loops); debug flag 8 or RT_MI355_JIT=0 keeps
     // the generic kernel, debug flag 16 or RT_MI355_JIT=2 specialises at the first render (A/B and parity tests); an unavailable hiprtc is not an error, the generic kernel renders the same image
     hipFunction_t jit = nullptr;
@@ -568,14 +604,19 @@ int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_cam
     if (!accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
         jit = jit_path_kernel(p->variant, H.slots, H.sruns, c->jit_note);
-    if ((rc = begin_timed(c, st))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
+    if ((rc = begin_timed(c, st, counters))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
     c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));
-    if (accel) { c->jit_note = "BVH walk (RT_OPT_ACCEL)"; launch_path_bvh(p->variant, D, A, target, slices, c->d_counters, st); }
-    else launch_path(p->variant, D, A, target, slices, c->d_counters, st, jit);
+    if (accel) { c->jit_note = "BVH walk (RT_OPT_ACCEL)"; launch_path_bvh(p->variant, D, A, target, slices, counters, st); }
+    else launch_path(p->variant, D, A, target, slices, counters, st, jit);
     HIPCHK(c, hipGetLastError());
-    if (slices > 1) { launch_sum_slices((const float4*)c->partial.p, (int)npx, slices, (float4*)d_accum, st); HIPCHK(c, hipGetLastError()); }
+    if (slices > 1) { launch_sum_slices(partial, (int)npx, slices, (float4*)d_accum, st); HIPCHK(c, hipGetLastError()); }
     c->pending_samples = (uint64_t)npx * (uint64_t)n_samples;
-    return end_timed(c, st);
+    return end_timed(c, st, counters, nullptr);
+}
+
+int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p,
+                                  int32_t width, int32_t height, float* d_accum, void* stream) {
+    return path_accumulate(c, scene, cam, p, width, height, d_accum, stream);
 }
 
 int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_whitted_params* p,
@@ -595,7 +636,7 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
     A.width = width; A.height = height; A.max_depth = p->max_depth; A.shadow_samples = p->shadow_samples; A.seed = p->seed;
     float fov_rad = (float)(cam->fov_deg / (180.0f / 3.14159265358979323846));       // 01 Main.cpp:333
     float th = tanf(fov_rad / 2.0f), w = (float)width, h = (float)height;
-    A.w = w; A.h = h; A.tan_half = th;
+    A.w = w; A.h = h; A.tan_half = th; A.debug_flags = c->debug_flags;
     // 02: nearly every ray is a shadow sample; for small scenes their scene query is compiled for THIS scene like the path
     // kernels' (same policy, same switches: second render of a scene, a large job, debug flag 16 / RT_MI355_JIT=2; flag 8 / =0 off)
     hipFunction_t jit = nullptr;

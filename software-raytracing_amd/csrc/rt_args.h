@@ -34,5 +34,6 @@ struct WhittedArgs {
     uint32_t seed;
     float w, h, tan_half;           // float(width), float(height), tanf(fovRadians/2) (01 Main.cpp:329-341)
     int stack_bytes, shadow_lds;    // set by launch_whitted: LDS bytes of the recursion stack; slot layout staged behind it for 02's shadow samples
+    int debug_flags;                // bit 6 (64): 02's shadow samples on the global-memory layout even when the slots would fit LDS (A/B switch)
 };
 } // namespace rt

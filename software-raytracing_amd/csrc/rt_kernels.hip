@@ -36,7 +36,7 @@ static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int
     else if (bytes <= RT_LDS_SCENE_MAX_BYTES && S.slot_bytes > 64 * 64)   // mid-size scene (beyond the specialised builds): LDS-resident, wave-level early-outs
         hipLaunchKernelGGL((k_path<VARIANT, true, true>), grid, dim3(256), bytes, st, S, A, out, counters);
     else if (bytes <= RT_LDS_SCENE_MAX_BYTES) hipLaunchKernelGGL((k_path<VARIANT, true>), grid, dim3(256), bytes, st, S, A, out, counters);  // small scene: LDS-resident
-    else                                     hipLaunchKernelGGL((k_path_tiled<VARIANT>), grid, dim3(256), RT_TILE_BYTES, st, S, A, out, counters);   // large scene: LDS-tiled
+    else                                     hipLaunchKernelGGL((k_path_tiled<VARIANT>), grid, dim3(256), RT_TILE_BYTES + SLOT_BYTES, st, S, A, out, counters);   // large scene: LDS-tiled
 }
 void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
     if (variant == 3) launch_path_v<3>(S, A, out, n_slices, counters, st, jit);
@@ -89,7 +89,7 @@ void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* 
     // the stack only ever holds the refraction child of a hit that ALSO reflects (0 < reflectToRefract < 1 on a material with
     // primaryToSecondary < 1): none of the reference's scenes has one, and then no LDS is spent on it (more blocks per CU)
     B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : 0;
-    B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed;
+    B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed && !(A.debug_flags & 64);
     if (soft && jit) {   // scene-specialised whitted_body<true>: its shadow samples need no staged slots
         WhittedArgs J = B; J.shadow_lds = 0;
         DevScene s = S;
@@ -97,7 +97,7 @@ void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* 
         if (hipModuleLaunchKernel(jit, grid.x, 1, 1, WBLOCK, 1, 1, (unsigned)J.stack_bytes, st, params, nullptr) == hipSuccess) return;
         (void)hipGetLastError();   // could not launch it: the generic kernel below renders the same image
     }
-    size_t lds = (size_t)B.stack_bytes + (B.shadow_lds ? (size_t)S.slot_bytes + 256 : 0);   // + one slot of slack for the read-ahead of wide slots
+    size_t lds = (size_t)B.stack_bytes + (B.shadow_lds ? (size_t)S.slot_bytes + 256 : 0);   // + the leading empty slot (address 0 = "no hit") and a wide slot of slack for read-ahead
     if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
     else      hipLaunchKernelGGL(k_whitted<false>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
 }

@@ -217,7 +217,10 @@ __device__ __forceinline__ void path_tiled_body(const DevScene& SD, const PathAr
     const int4* __restrict__ chunks = reinterpret_cast<const int4*>(SD.blob + SD.off_chunks);
     const SceneMem<false> G{reinterpret_cast<const char*>(SD.blob)};
     const SceneMem<true> T{reinterpret_cast<const char*>(smem)};
-    const uint32_t tile0 = T.at(0U);
+    // chunks are staged one slot past the start of LDS: closest_hit_runs reports the winner as its LDS address and 0 means
+    // "nothing hit", so no slot may sit at address 0 (the launch reserves RT_TILE_BYTES + SLOT_BYTES)
+    const uint32_t tile0 = T.at((uint32_t)SLOT_BYTES);
+    float4* const tile = smem + SLOT_BYTES / 16;
     int px, py;
     bool inside = pixel_of_thread(A.width, A.height, px, py);
     const int slice = blockIdx.y;
@@ -241,7 +244,7 @@ __device__ __forceinline__ void path_tiled_body(const DevScene& SD, const PathAr
             const int4 ch = chunks[c];
             const float4* __restrict__ src = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(SD.blob) + ch.x);
             if (c) __syncthreads();                 // everyone is done with the previous chunk
-            for (int i = threadIdx.x; i < (ch.y >> 4); i += 256) smem[i] = src[i];
+            for (int i = threadIdx.x; i < (ch.y >> 4); i += 256) tile[i] = src[i];
             __syncthreads();
             if (L.alive) {
                 uint32_t b = 0U;

@@ -19,11 +19,13 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
     // fast tests of the path kernels (see fastshadow in rt_strict.h for why that is safe); A.shadow_lds = 0 when the
     // scene is too large for that
     const SceneMem<true> T{reinterpret_cast<const char*>(stk_raw)};
-    const uint32_t sh_slots = T.at((uint32_t)A.stack_bytes);
+    // the staged slots start one slot past the stack so that no slot ever sits at LDS address 0: closest_hit_runs reports
+    // the winner as its address and 0 means "nothing hit" (with no stack, stack_bytes = 0, the first slot would be at 0)
+    const uint32_t sh_slots = T.at((uint32_t)A.stack_bytes + SLOT_BYTES);
     const int4* __restrict__ sruns = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
 #ifndef RT_JIT_SCENE
     if (SOFT && A.shadow_lds) {
-        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(stk_raw) + A.stack_bytes);
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(stk_raw) + A.stack_bytes + SLOT_BYTES);
         const float4* src = SD.blob + SD.off_slots;
         for (int i = threadIdx.x; i < (SD.slot_bytes >> 4); i += WBLOCK) dst[i] = src[i];
         __syncthreads();

@@ -6,14 +6,32 @@
 #pragma once
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include "RtBackend.hpp"
 
 class ProgressiveFrame {
-    struct Header { char magic[8]; uint32_t width, height, spp, done, seed, variant; };
+    struct Header { char magic[8]; uint32_t width, height, spp, done, seed, variant; uint64_t scene_hash; };
     uint32_t width_, height_, spp_, done_ = 0, seed_, variant_;
+    uint64_t scene_hash_ = 0;   // FNV-1a of the scene records and the camera the sums belong to (0 = nothing accumulated yet)
+    static uint64_t fnv(uint64_t h, const void* p, size_t n) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ULL; }
+        return h;
+    }
+    // The sums of one frame belong to one scene and one camera: mixing in samples of another is refused.
+    void bind(const rt_scene& scene, const rt_camera& cam) {
+        uint64_t h = 1469598103934665603ULL;
+        h = fnv(h, scene.prims, static_cast<size_t>(scene.n_prims) * sizeof(rt_prim));
+        h = fnv(h, scene.materials, static_cast<size_t>(scene.n_materials) * sizeof(rt_material));
+        h = fnv(h, &cam, sizeof cam);
+        if (h == 0) h = 1;
+        if (scene_hash_ != 0 && scene_hash_ != h) throw std::runtime_error("ERROR: ProgressiveFrame holds samples of another scene or camera");
+        scene_hash_ = h;
+    }
     std::vector<float> mean_;   // width*height*3: sum over the samples done so far / spp
 public:
     ProgressiveFrame(unsigned width, unsigned height, unsigned spp, uint32_t seed, int variant)
@@ -23,7 +41,8 @@ public:
 
     // Renders the next 'count' samples of every pixel and adds them.
     void accumulate(const rt_scene& scene, const rt_camera& cam, unsigned count) {
-        if (complete()) return;
+        if (complete() || count == 0) return;      // an empty range is not (0, 0): rt_path_params reads that as "the whole frame"
+        bind(scene, cam);
         rt_path_params prm;
         rtbackend::check(rt_path_params_default(static_cast<int32_t>(variant_), &prm));
         prm.spp = static_cast<int32_t>(spp_); prm.seed = seed_;
@@ -47,7 +66,7 @@ public:
     void save(const std::string& path) const {
         FILE* f = std::fopen(path.c_str(), "wb");
         if (!f) throw std::runtime_error("ERROR: can't open " + path);
-        Header h{{'R', 'T', 'P', 'R', 'O', 'G', '1', 0}, width_, height_, spp_, done_, seed_, variant_};
+        Header h{{'R', 'T', 'P', 'R', 'O', 'G', '2', 0}, width_, height_, spp_, done_, seed_, variant_, scene_hash_};
         std::fwrite(&h, sizeof h, 1, f); std::fwrite(mean_.data(), sizeof(float), mean_.size(), f);
         std::fclose(f);
     }
@@ -56,12 +75,12 @@ public:
         FILE* f = std::fopen(path.c_str(), "rb");
         if (!f) return false;
         Header h{};
-        bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "RTPROG1", 8) == 0 && h.width == width_ && h.height == height_ &&
+        bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "RTPROG2", 8) == 0 && h.width == width_ && h.height == height_ &&
                   h.spp == spp_ && h.seed == seed_ && h.variant == variant_ && h.done <= spp_ &&
                   std::fread(mean_.data(), sizeof(float), mean_.size(), f) == mean_.size();
         std::fclose(f);
         if (!ok) throw std::runtime_error("ERROR: " + path + " is not a checkpoint of this frame");
-        done_ = h.done;
+        done_ = h.done; scene_hash_ = h.scene_hash;     // the next accumulate() checks its scene and camera against it
         return true;
     }
 };

@@ -9,8 +9,15 @@ ranges over 8 threads (04_PathTracingLights/Main.cpp:399-420); sample ranges bal
 def sample_range(rank, world, spp):
     if not (0 <= rank < world) or spp < 0:
         raise ValueError("bad rank/world/spp")
-    return rank * spp // world, (rank + 1) * spp // world
+    b, e = rank * spp // world, (rank + 1) * spp // world
+    # rt_path_params reads (0, 0) as "the whole frame": an EMPTY share (spp < world) must not look like that, or its
+    # rank would render every sample and the all-reduced frame would count them twice.  [spp, spp) is empty and explicit.
+    return (b, e) if e > b else (spp, spp)
 
 
 def all_ranges(world, spp):
     return [sample_range(r, world, spp) for r in range(world)]
+
+
+def is_empty(rng):
+    return rng[1] <= rng[0]

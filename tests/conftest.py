@@ -7,6 +7,7 @@ import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))     # orc.py: the checker's binding
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

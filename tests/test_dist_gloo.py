@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
-from rtamd import abi, oracle, scenes, shard  # noqa: E402
+from rtamd import abi, scenes, shard
+import orc as oracle
 
 W, H, SPP = 64, 40, 7      # odd spp: ragged ranges
 
@@ -40,8 +41,12 @@ def test_ranges_cover_every_sample_once():
     for world in (1, 2, 3, 4, 8):
         for spp in (0, 1, 7, 32, 1024, 1000):
             r = shard.all_ranges(world, spp)
-            assert r[0][0] == 0 and r[-1][1] == spp and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            full = [x for x in r if not shard.is_empty(x)]
+            assert sum(e - b for b, e in r) == spp and all(a[1] == b[0] for a, b in zip(full, full[1:]))
+            assert (not full) or (full[0][0] == 0 and full[-1][1] == spp)
             assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+            # rt_path_params reads (0, 0) as "the whole frame": no share may look like that unless it IS the whole frame
+            assert all(x != (0, 0) or spp == 0 for x in r)
     with pytest.raises(ValueError):
         shard.sample_range(2, 2, 8)
 

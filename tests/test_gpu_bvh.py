@@ -8,7 +8,8 @@ arbitrary orientations, triangles, planes (unbounded: outside the tree), empty s
 import numpy as np
 import pytest
 
-from rtamd import abi, oracle, scenes
+from rtamd import abi, scenes
+import orc as oracle
 
 pytestmark = pytest.mark.gpu
 

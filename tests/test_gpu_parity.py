@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 
 from conftest import frac_within, load_png_rgb
-from rtamd import abi, lib, oracle, scenes
+from rtamd import abi, lib, scenes
+import orc as oracle
 
 pytestmark = pytest.mark.gpu
 W, H = 784, 561
@@ -45,6 +46,40 @@ def test_02_shadow_sample_sweep(ctx, samples):
     assert g["shadow_rays"] == o["shadow_rays"] == samples * w * h      # exactly 1 + samples rays per pixel
     assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.998
     assert abs(g["rgb"].mean() - o["rgb"].mean()) < 1e-4
+
+
+def test_02_first_primitive_casts_shadows(ctx):
+    """The only occluder is primitive 0 and no material branches (no LDS stack): with the shadow slots staged at LDS address 0
+    the generic kernel once took "winner at address 0" for "nothing hit" and lost this sphere's shadow.  The
+    generic kernel with and without LDS staging, the scene-specialised kernel and the oracle must agree."""
+    s = scenes.Scene()
+    rubber = s.phong((0.6, 0.2, 0.2), 0.1, 16.0); white = s.phong((1, 1, 1), 0.0)
+    s.sphere(rubber, (0, -6.5, -15), 3.0)
+    s.plane(white, (0, -10, 0), (0, 1, 0)); s.plane(white, (0, 0, -20), (0, 0, 1))
+    s.light((0, 6.5, -10), (0.9, 0.9, 0.9), 3.0)
+    cam, prm = scenes.camera(90.0), scenes.whitted_params(4, 16, seed=2)
+    w, h = 196, 140
+    o = oracle.render_whitted(s, cam, prm, w, h, threads=8)
+    lit = scenes.Scene()                                      # the same scene without the sphere: what a lost shadow looks like
+    lit.phong((0.6, 0.2, 0.2), 0.1, 16.0); lw = lit.phong((1, 1, 1), 0.0)
+    lit.plane(lw, (0, -10, 0), (0, 1, 0)); lit.plane(lw, (0, 0, -20), (0, 0, 1)); lit.light((0, 6.5, -10), (0.9, 0.9, 0.9), 3.0)
+    o_lit = oracle.render_whitted(lit, cam, prm, w, h, threads=8)
+    shadowed = (o_lit["rgb"].sum(axis=-1) - o["rgb"].sum(axis=-1)) > 0.2      # floor pixels the sphere darkens
+    assert shadowed.sum() > 200
+    imgs = {}
+    for name, flags in (("generic_lds", 8), ("generic_global", 8 | 64), ("specialised", 16)):
+        ctx.set_debug_flags(flags)
+        try:
+            g = ctx.render_whitted(s, cam, prm, w, h)
+            assert ctx.last_whitted_kernel() == (2 if name == "specialised" else 1)
+        finally:
+            ctx.set_debug_flags(0)
+        assert (g["rays"], g["shadow_rays"]) == (o["rays"], o["shadow_rays"]), name
+        assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.998, name
+        assert frac_within(g["rgb"][shadowed], o["rgb"][shadowed], 1e-4) >= 0.99, name
+        imgs[name] = g["rgb"]
+    assert np.array_equal(imgs["generic_lds"], imgs["specialised"])
+    assert frac_within(imgs["generic_global"], imgs["generic_lds"], 1e-4) >= 0.998
 
 
 def test_whitted_recursion_tree_both_branches(ctx):

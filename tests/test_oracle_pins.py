@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from conftest import load_png_rgb
-from rtamd import abi, oracle, scenes
+from rtamd import abi, scenes
+import orc as oracle
 
 W, H = 784, 561
 

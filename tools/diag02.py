@@ -2,7 +2,9 @@ import os, sys
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
-from rtamd import lib, oracle, scenes
+sys.path.insert(0, os.path.join(ROOT, "oracle"))     # orc.py: the checker's binding
+from rtamd import lib, scenes
+import orc as oracle
 ctx = lib.Context()
 for S in (1, 4):
     s, cam, prm = scenes.scene02(S, seed=1)

@@ -2,7 +2,9 @@ import os, sys
 import numpy as np, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
-from rtamd import lib, scenes, oracle, abi
+sys.path.insert(0, os.path.join(ROOT, "oracle"))     # orc.py: the checker's binding
+from rtamd import lib, scenes, abi
+import orc as oracle
 ctx = lib.Context()
 full, cam, _ = scenes.scene_stress(n_spheres=600, grid=12, spp=4, seed=3)
 s = scenes.Scene()

@@ -7,7 +7,9 @@ import numpy as np
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
-from rtamd import abi, lib, oracle, scenes  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "oracle"))     # orc.py: the checker's binding
+from rtamd import abi, lib, scenes
+import orc as oracle
 
 
 def cmp_rgb(name, g, o, tol=1e-4):

@@ -3,7 +3,9 @@ import torch
 import numpy as np
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'software-raytracing_amd'))
-from rtamd import scenes, oracle, abi
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
+from rtamd import scenes, abi
+import orc as oracle
 f32=np.float32
 L=oracle.lib()
 FP=C.POINTER(C.c_float)
