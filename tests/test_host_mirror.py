@@ -178,7 +178,7 @@ def test_progressive_checkpointed_render_equals_one_shot(tmp_path):
     one, prog, ck = str(tmp_path / "one.ppm"), str(tmp_path / "prog.ppm"), str(tmp_path / "frame.ckpt")
     subprocess.run(base + ["--out", one], check=True, capture_output=True, timeout=120)
     p1 = subprocess.run(base + ["--chunk", "10", "--checkpoint", ck, "--stop-after", "20", "--out", str(tmp_path / "half.ppm")], check=True, capture_output=True, text=True, timeout=120)
-    assert "INFO: 20 of 48 samples per pixel done" in p1.stdout and os.path.getsize(ck) == 32 + w * h * 3 * 4
+    assert "INFO: 20 of 48 samples per pixel done" in p1.stdout and os.path.getsize(ck) == 40 + w * h * 3 * 4      # header (magic, frame, scene+camera hash) + float sums
     p2 = subprocess.run(base + ["--chunk", "10", "--checkpoint", ck, "--out", prog], check=True, capture_output=True, text=True, timeout=120)
     assert "INFO: Resumed at sample 20" in p2.stdout and "INFO: 48 of 48 samples per pixel done" in p2.stdout
     a, b = _read_ppm(one).astype(int), _read_ppm(prog).astype(int)
