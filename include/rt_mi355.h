@@ -213,6 +213,23 @@ int32_t rt_render_path(rt_ctx* ctx, const rt_scene* scene, const rt_camera* came
 int32_t rt_path_accumulate_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* camera,
                                   const rt_path_params* params, int32_t width, int32_t height,
                                   float* d_accum, void* stream);
+/* rt_path_accumulate_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same result as
+ * rt_path_accumulate_device, but everything the kernels need beyond the caller's buffers - the flattened scene, the ray
+ * counters and the per-slice partial sums - lives in ONE fixed array that is part of the library's code object (a
+ * static __device__ array; every GPU the library runs on holds its own copy from module load to process end), and this
+ * call makes no hipMalloc / hipFree / hipHostMalloc and compiles nothing (it always runs the generic kernels, brute force).
+ * Limits (rt_noalloc_limits): the flattened scene must fit scene_bytes (64 KiB: about 700 spheres/planes or 400
+ * rectangles/triangles; larger -> RT_ERR_TOO_LARGE); the partial sums use at most partial_bytes (32 MiB): an image too large
+ * for several slices is rendered with fewer, or written straight into d_accum - any width*height the other entry point takes.
+ * RT_OPT_ACCEL must be RT_ACCEL_NONE (else RT_ERR_UNSUPPORTED).
+ * All calls on one GPU - from any context, any stream - share that GPU's array, which keeps the last call's contents:
+ * calls that overlap in time on one GPU race; finish one (rt_sync) before the next starts. */
+int32_t rt_path_accumulate_device_noalloc(rt_ctx* ctx, const rt_scene* scene, const rt_camera* camera,
+                                          const rt_path_params* params, int32_t width, int32_t height,
+                                          float* d_accum, void* stream);
+/* The fixed sizes above, in bytes (either pointer may be NULL). */
+int32_t rt_noalloc_limits(int32_t* scene_bytes, int32_t* partial_bytes);
 /* color: width*height float4 (R,G,B,1), OVERWRITTEN. */
 int32_t rt_whitted_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* camera,
                           const rt_whitted_params* params, int32_t width, int32_t height,

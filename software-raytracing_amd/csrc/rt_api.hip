@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "rt_device.h"
@@ -17,7 +18,21 @@
 
 using namespace rt;
 
+// ---- scratch of the allocation-free entry point (rt_path_accumulate_device_noalloc) ---------------------------------------
+// One fixed array per GPU, part of the code object: every GPU the library runs on holds it from module load until the process
+// ends.  Layout: [scene blob | ray counters | per-slice partial sums].  In host code the NAME 'scratch' is only a stand-in for
+// the symbol, not a device address: rt_create() asks hipGetSymbolAddress for the address on ITS device (each GPU has its own
+// copy at its own address) and keeps it in g_scratch_ptr[device]; host code only ever uses that pointer.
+#define RT_NOALLOC_SCENE_BYTES   (64u * 1024u)                 /* flattened scene incl. materials: about 700 spheres/planes */
+#define RT_NOALLOC_COUNTER_BYTES (RT_COUNTER_WORDS * 8u)
+#define RT_NOALLOC_PARTIAL_BYTES (32u * 1024u * 1024u)         /* per-slice partial images (width*height*16 B each) */
+#define RT_NOALLOC_SCRATCH_BYTES (RT_NOALLOC_SCENE_BYTES + RT_NOALLOC_COUNTER_BYTES + RT_NOALLOC_PARTIAL_BYTES)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 namespace {
+constexpr int RT_MAX_DEVICES = 64;
+unsigned char* g_scratch_ptr[RT_MAX_DEVICES] = {};       // device address of 'scratch' per HIP device, filled by rt_create
+std::mutex g_scratch_mu;
 
 thread_local std::string g_create_error;
 
@@ -107,6 +122,9 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_scene_use = nullptr;            // recorded behind the last work that reads scene_buf / h_stage, on whichever stream it ran
+    // allocation-free entry point: this device's copy of 'scratch', a fixed pinned staging buffer for its scene blob (both
+    // set up once by rt_create) and the event behind the last kernel that read them
+    unsigned char* scratch_dev = nullptr; void* h_stage_na = nullptr; hipEvent_t ev_scene_use_na = nullptr;
     bool timing_pending = false;
     DevBuf scene_buf, partial, accum, bgra, rgb;
     unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
@@ -494,6 +512,18 @@ rt_ctx* rt_create(int32_t device_id) {
               hipEventCreate(&c->ev1) == hipSuccess && hipEventCreateWithFlags(&c->ev_scene_use, hipEventDisableTiming) == hipSuccess && hipMalloc((void**)&c->d_counters, RT_COUNTER_WORDS * sizeof(unsigned long long)) == hipSuccess &&
               hipHostMalloc((void**)&c->h_counters, RT_COUNTER_WORDS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
     if (!ok) { g_create_error = "failed to create stream/events/counters"; rt_destroy(c); return nullptr; }
+    {   // set-up of the allocation-free entry point, once per device, with that device current
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (dev < RT_MAX_DEVICES && !g_scratch_ptr[dev]) {
+            unsigned char* ptr = nullptr;
+            hipError_t se = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+            if (se != hipSuccess || !ptr) { g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se); rt_destroy(c); return nullptr; }
+            g_scratch_ptr[dev] = ptr;
+        }
+        c->scratch_dev = dev < RT_MAX_DEVICES ? g_scratch_ptr[dev] : nullptr;
+    }
+    if (hipHostMalloc(&c->h_stage_na, RT_NOALLOC_SCENE_BYTES, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_scene_use_na, hipEventDisableTiming) != hipSuccess) { g_create_error = "failed to create the allocation-free entry point's staging buffer"; rt_destroy(c); return nullptr; }
     memset(c->h_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long));
     return c;
 }
@@ -509,6 +539,8 @@ void rt_destroy(rt_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_scene_use) (void)hipEventDestroy(c->ev_scene_use);
+    if (c->ev_scene_use_na) (void)hipEventDestroy(c->ev_scene_use_na);
+    if (c->h_stage_na) (void)hipHostFree(c->h_stage_na);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -559,8 +591,10 @@ int32_t rt_sync(rt_ctx* c, void* stream) {
     return RT_OK;
 }
 
+// noalloc: the body of rt_path_accumulate_device_noalloc - scene blob, ray counters and per-slice partial sums live in this
+// device's 'scratch' array, the generic (precompiled) kernels run, and no HIP allocation or free happens on any path below.
 static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p,
-                               int32_t width, int32_t height, float* d_accum, void* stream) {
+                               int32_t width, int32_t height, float* d_accum, void* stream, bool noalloc) {
     int rc = check_ctx(c); if (rc) return rc;
     if (!cam || !p || !d_accum || width <= 0 || height <= 0) return fail(c, RT_ERR_BAD_ARG, "rt_path_accumulate_device: null pointer or non-positive size");
     if ((long long)width * height > (1LL << 28)) return fail(c, RT_ERR_TOO_LARGE, "image larger than 2^28 pixels");
@@ -571,8 +605,20 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const bool accel = c->accel == 1;
     const HostScene* Hp = nullptr; DevScene D;
+    HostScene na_H;
     unsigned long long* counters = c->d_counters;
-    if ((rc = prepare_scene(c, scene, p->variant, accel, st, Hp, D))) return rc;
+    if (noalloc) {
+        if (accel) return fail(c, RT_ERR_UNSUPPORTED, "rt_path_accumulate_device_noalloc: brute force only (RT_OPT_ACCEL must be RT_ACCEL_NONE)");
+        if (!c->scratch_dev) return fail(c, RT_ERR_HIP, "rt_path_accumulate_device_noalloc: no scratch array on this device");
+        if ((rc = compile_scene(c, scene, p->variant, na_H))) return rc;
+        const BlobLayout L = blob_layout(na_H);
+        if (L.total > RT_NOALLOC_SCENE_BYTES)
+            return fail(c, RT_ERR_TOO_LARGE, "rt_path_accumulate_device_noalloc: flattened scene is " + std::to_string(L.total) + " bytes, the fixed scratch holds " +
+                        std::to_string(RT_NOALLOC_SCENE_BYTES) + " (use rt_path_accumulate_device)");
+        if ((rc = fill_and_upload_scene(c, na_H, L, st, D, (char*)c->h_stage_na, c->scratch_dev, c->ev_scene_use_na))) return rc;
+        Hp = &na_H;
+        counters = reinterpret_cast<unsigned long long*>(c->scratch_dev + RT_NOALLOC_SCENE_BYTES);
+    } else if ((rc = prepare_scene(c, scene, p->variant, accel, st, Hp, D))) return rc;
     const HostScene& H = *Hp;
 
     PathArgs A{};
@@ -590,20 +636,26 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     int n_samples = s1 - s0;
     int slices = n_samples > 0 ? pick_slices(width, height, n_samples) : 1;
     size_t npx = (size_t)width * height;
+    if (noalloc) {   // the partial images must fit the fixed scratch: fewer slices, or none (the kernel then writes d_accum directly)
+        const size_t fit = RT_NOALLOC_PARTIAL_BYTES / (npx * sizeof(float4));
+        if ((size_t)slices > fit) slices = fit >= 2 ? (int)fit : 1;
+    }
     A.slice_len = n_samples > 0 ? (n_samples + slices - 1) / slices : 1;
     slices = n_samples > 0 ? (n_samples + A.slice_len - 1) / A.slice_len : 1;
     float4* target = (float4*)d_accum;
     float4* partial = nullptr;
-    if (slices > 1) { HIPCHK(c, c->partial.reserve(npx * slices * sizeof(float4))); partial = (float4*)c->partial.p; }
+    if (slices > 1 && noalloc) partial = reinterpret_cast<float4*>(c->scratch_dev + RT_NOALLOC_SCENE_BYTES + RT_NOALLOC_COUNTER_BYTES);
+    else if (slices > 1) { HIPCHK(c, c->partial.reserve(npx * slices * sizeof(float4))); partial = (float4*)c->partial.p; }
     if (slices > 1) target = partial;
     // small scenes: the scene query compiled for THIS scene (literal operands, no loops); debug flag 8 or RT_MI355_JIT=0 keeps
     // the generic kernel, debug flag 16 or RT_MI355_JIT=2 specialises at the first render (A/B and parity tests); an unavailable hiprtc is not an error, the generic kernel renders the same image
     hipFunction_t jit = nullptr;
     const char* jit_env = getenv("RT_MI355_JIT");
     c->jit_note.clear();
-    if (!accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
+    if (!noalloc && !accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
         jit = jit_path_kernel(p->variant, H.slots, H.sruns, c->jit_note);
+    if (noalloc) c->jit_note = "allocation-free entry point: generic kernel";
     if ((rc = begin_timed(c, st, counters))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
     c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));
     if (accel) { c->jit_note = "BVH walk (RT_OPT_ACCEL)"; launch_path_bvh(p->variant, D, A, target, slices, counters, st); }
@@ -611,12 +663,21 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     HIPCHK(c, hipGetLastError());
     if (slices > 1) { launch_sum_slices(partial, (int)npx, slices, (float4*)d_accum, st); HIPCHK(c, hipGetLastError()); }
     c->pending_samples = (uint64_t)npx * (uint64_t)n_samples;
-    return end_timed(c, st, counters, nullptr);
+    return end_timed(c, st, counters, noalloc ? c->ev_scene_use_na : nullptr);
 }
 
 int32_t rt_path_accumulate_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p,
                                   int32_t width, int32_t height, float* d_accum, void* stream) {
-    return path_accumulate(c, scene, cam, p, width, height, d_accum, stream);
+    return path_accumulate(c, scene, cam, p, width, height, d_accum, stream, false);
+}
+int32_t rt_path_accumulate_device_noalloc(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p,
+                                          int32_t width, int32_t height, float* d_accum, void* stream) {
+    return path_accumulate(c, scene, cam, p, width, height, d_accum, stream, true);
+}
+int32_t rt_noalloc_limits(int32_t* scene_bytes, int32_t* partial_bytes) {
+    if (scene_bytes) *scene_bytes = (int32_t)RT_NOALLOC_SCENE_BYTES;
+    if (partial_bytes) *partial_bytes = (int32_t)RT_NOALLOC_PARTIAL_BYTES;
+    return RT_OK;
 }
 
 int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_whitted_params* p,

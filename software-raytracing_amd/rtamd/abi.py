@@ -70,5 +70,5 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_get_stats", "rt_abi_version",
     "rt_whitted_params_default", "rt_path_params_default",
     "rt_render_whitted", "rt_render_path",
-    "rt_path_accumulate_device", "rt_whitted_device", "rt_resolve_device", "rt_sync", "rt_set_option",
+    "rt_path_accumulate_device", "rt_path_accumulate_device_noalloc", "rt_noalloc_limits", "rt_whitted_device", "rt_resolve_device", "rt_sync", "rt_set_option",
 ]

@@ -38,6 +38,8 @@ def load():
         L.rt_render_path.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_path_params), P(abi.rt_image)]
         L.rt_path_accumulate_device.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_path_params),
                                                 C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.rt_path_accumulate_device_noalloc.argtypes = L.rt_path_accumulate_device.argtypes
+        L.rt_noalloc_limits.argtypes = [P(C.c_int32), P(C.c_int32)]
         L.rt_whitted_device.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_whitted_params),
                                         C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
@@ -104,6 +106,10 @@ class Context:
     def path_accumulate_device(self, scene, cam, prm, width, height, d_accum_ptr, stream=None):
         sc = scene.c()
         self._chk(self.L.rt_path_accumulate_device(self.h, C.byref(sc), C.byref(cam), C.byref(prm), width, height, d_accum_ptr, stream))
+
+    def path_accumulate_device_noalloc(self, scene, cam, prm, width, height, d_accum_ptr, stream=None):
+        sc = scene.c()
+        self._chk(self.L.rt_path_accumulate_device_noalloc(self.h, C.byref(sc), C.byref(cam), C.byref(prm), width, height, d_accum_ptr, stream))
 
     def whitted_device(self, scene, cam, prm, width, height, d_color_ptr, stream=None):
         sc = scene.c()

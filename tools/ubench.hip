@@ -100,6 +100,29 @@ KERNEL(k_min_u32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = th
 KERNEL(k_and_or, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
 KERNEL(k_dsread, float x[CHAINS]; __shared__ float4 sm[64]; if (threadIdx.x < 64) sm[threadIdx.x] = make_float4(a, b, a, b); __syncthreads(); unsigned ad = (unsigned)(uintptr_t)sm & 0xffffu; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, { float4 v; asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ad)); x[c] += v.x; })
 
+KERNEL(k_fmaak, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f8ccccd" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_fmamk, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_fmamk_f32 %0, %0, 0x3f8ccccd, %1" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_min3, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b)))
+KERNEL(k_sub_u32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_sub_lit, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_sub_f32 %0, 0x40a00000, %0" : "+v"(x[c])))
+KERNEL(k_cnd_vcc2, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x[c]) : "v"(a), "v"(b)))
+KERNEL(k_cmp_cnd_cnd, float x[CHAINS]; float y[CHAINS]; for (int c = 0; c < CHAINS; ++c) { x[c] = threadIdx.x + c; y[c] = c; }, asm volatile("v_cmp_lt_f32 vcc, %0, %2\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %1, %1, %2, vcc" : "+v"(x[c]), "+v"(y[c]) : "v"(a), "v"(b) : "vcc"))
+KERNEL(k_min_u32_andor, unsigned x[CHAINS]; unsigned y[CHAINS]; for (int c = 0; c < CHAINS; ++c) { x[c] = threadIdx.x + c; y[c] = c; }, asm volatile("v_and_or_b32 %1, %1, %2, %3\n\tv_min_u32 %0, %0, %1" : "+v"(x[c]), "+v"(y[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
+KERNEL(k_mov_dpp, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[c])))
+KERNEL(k_xor_sdwa, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(x[c])))
+KERNEL(k_add_salu, float x[CHAINS]; int sacc = 0; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_add_f32 %0, %0, %2\n\ts_add_i32 %1, %1, 1" : "+v"(x[c]), "+s"(sacc) : "v"(a)))
+KERNEL(k_add_2salu, float x[CHAINS]; int sacc = 0; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_add_f32 %0, %0, %2\n\ts_add_i32 %1, %1, 1\n\ts_add_i32 %1, %1, 1" : "+v"(x[c]), "+s"(sacc) : "v"(a)))
+KERNEL(k_fma_neg, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_fma_f32 %0, %0, %1, -%2" : "+v"(x[c]) : "v"(a), "v"(b)))
+KERNEL(k_mul_e64neg, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_mul_f32_e64 %0, %0, -%1" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_max_abs, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_max_f32_e64 %0, |%0|, %1" : "+v"(x[c]) : "v"(a)))
+KERNEL(k_cvt_ubyte, float x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(x[c])))
+KERNEL(k_cmp_lt_u32_s, unsigned x[CHAINS]; unsigned long long m; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_cmp_lt_u32_e64 %1, %0, %2" : "+v"(x[c]), "=s"(m) : "v"(__float_as_uint(a))))
+KERNEL(k_bfe, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(x[c])))
+KERNEL(k_max_u32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_max_u32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_min_i32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_min_i32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_min3_u32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
+KERNEL(k_add3, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
+
 template <typename K>
 void run(const char* name, K k, float* d, double ops_per_instr) {
     int blocks = 256 * 8;
@@ -131,6 +154,12 @@ int main() {
     run("v_pk_mul_f32", k_pkmul, d, 2); run("v_pk_add_f32", k_pkadd, d, 2);
     run("sqrt+3fmac", k_sqrt_fmac3, d, 7); run("cmp+2fmac", k_cmp_fmac2, d, 5); run("v_mul literal", k_mul_lit, d, 1); run("v_cmp_le_u32", k_cmp_u32, d, 1);
     run("v_min_u32", k_min_u32, d, 1); run("v_and_or_b32", k_and_or, d, 1); run("ds_read_b128 same addr (+add)", k_dsread, d, 1);
+    run("v_fmaak_f32 (lit)", k_fmaak, d, 2); run("v_fmamk_f32 (lit)", k_fmamk, d, 2); run("v_min3_f32", k_min3, d, 1); run("v_sub_u32", k_sub_u32, d, 1);
+    run("v_sub_f32 lit", k_sub_lit, d, 1); run("v_cndmask vcc (no dep)", k_cnd_vcc2, d, 1); run("cmp+2cndmask", k_cmp_cnd_cnd, d, 3); run("and_or+min_u32", k_min_u32_andor, d, 2);
+    run("s_nop1+v_mov_dpp", k_mov_dpp, d, 1); run("v_xor_sdwa", k_xor_sdwa, d, 1); run("v_add+s_add", k_add_salu, d, 1); run("v_add+2s_add", k_add_2salu, d, 1);
+    run("v_fma neg mod", k_fma_neg, d, 2); run("v_mul_e64 neg", k_mul_e64neg, d, 1); run("v_max_e64 abs", k_max_abs, d, 1); run("v_cvt_f32_ubyte0", k_cvt_ubyte, d, 1);
+    run("v_cmp_lt_u32_e64->s", k_cmp_lt_u32_s, d, 1); run("v_bfe_u32", k_bfe, d, 1); run("v_max_u32", k_max_u32, d, 1); run("v_min_i32", k_min_i32, d, 1); run("v_min3_u32", k_min3_u32, d, 1);
+    run("v_add3_u32", k_add3, d, 1);
     hipLaunchKernelGGL(k_clock, dim3(2048), dim3(256), 0, 0, d, 1.0001f, 0.5f); hipDeviceSynchronize();
     hipFree(d);
     return 0;
