@@ -63,16 +63,8 @@ def test_03_ray_ratio_and_hollow_glass_screenshot(recorded):
     assert np.allclose(blocks(mine).mean(axis=(0, 1)), blocks(png).mean(axis=(0, 1)), rtol=0.01)
 
 
-def test_04_image_statistics_match_the_reference_run(recorded):
-    s, cam, prm = scenes.scene04(32, seed=11)
-    r = oracle.render_path(s, cam, prm, W, H, threads=4)
-    b = r["bgra"][:, :, 2::-1].astype(np.float64) / 255
-    black = (r["bgra"][:, :, :3].max(axis=2) == 0).mean()
-    assert abs(black - 0.3485) < 0.004
-    ref = np.array(recorded["survey"]["04_32spp_784x561_mean_sq_byte_rgb_1core"])
-    assert np.allclose((b ** 2).mean(axis=(0, 1)), ref, rtol=0.015)
-    ratio = r["rays"] / (W * H * 32)
-    assert 6.80 < ratio < 6.90      # ~6.86 rays/sample
+# 04's image-level pin is tests/test_converged_goldens.py: a converged image rendered by the reference's own scene, material
+# and sampler code (oracle/gen_converged.py), not numbers measured outside this repository.
 
 
 def test_quirks_are_kept():
