@@ -10,7 +10,8 @@ all-reduce over xGMI before the resolve; total work is fixed, so scaling is "str
 
 Prints ONE JSON line (rank 0).  roofline: FP32 VALU (no MFMA on this path), algorithmic FLOPs per ray
 from SURVEY.md 8(d) (04 scene: 249) x rays the kernel counted / the kernel's HIP-event duration.
-cpu_baseline: the CPU oracle (a restatement, kind "port") on a band of rows of the same frame."""
+cpu_baseline: the reference's own code (oracle/_ref/libref_e4.so, kind "reference") on 16 host processes, one row of the same
+frame each; if that library is absent, the CPU oracle (a restatement, kind "port") on a band of rows."""
 import argparse
 import json
 import os
@@ -24,6 +25,28 @@ sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))     # orc.py: the checker's binding
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (vector)"
+
+
+def cpu_baseline_reference(width, height, spp, procs):
+    """The REFERENCE's own 04 code (oracle/_ref/libref_e4.so, built from /root/reference by oracle/Makefile and shipped as a
+    built library) on `procs` host processes, one row of the same frame each; run as a child process that never touches
+    the GPU.  None when the library is not there (then the port is timed instead)."""
+    import subprocess
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libref_e4.so")
+    if not os.path.exists(lib_path):
+        return None
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_rate.py"), "--width", str(width), "--height", str(height),
+                              "--spp", str(spp), "--procs", str(procs), "--rows-per-proc", "1"], check=True, capture_output=True, text=True, timeout=600)
+        m = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:      # the baseline is a reported figure, never a reason to lose the bench line
+        print(f"cpu_baseline (reference) failed: {e}", file=sys.stderr)
+        return None
+    return {"value": m["rays_per_s"], "unit": "rays/s", "cores": procs, "kind": "reference",
+            "sample": f"the reference's own 04 code (scene::List::intersectsRay, Materials/*.hpp, RndHemisphereVec3, its <random> engines; g++ -O2, "
+                      f"oracle/_ref/libref_e4.so) driven by the TraceTay-following loop of oracle/ref_harness_e4.cpp: rows {m['rows'][0]}..{m['rows'][1]} of the same "
+                      f"{width}x{height} frame at {spp} spp, one row per process: {m['rays']} rays in {m['seconds']:.1f} s on {procs} processes "
+                      f"({m['rays_per_s'] / procs / 1e6:.2f} Mrays/s per core)"}
 
 
 def cpu_baseline(scenes, width, height, spp, rows, threads):
@@ -184,7 +207,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(scenes, W, H, SPP, args.cpu_rows, threads)
+            out["cpu_baseline"] = cpu_baseline_reference(W, H, SPP, threads) or cpu_baseline(scenes, W, H, SPP, args.cpu_rows, threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -649,12 +649,23 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     if (slices > 1) target = partial;
     // small scenes: the scene query compiled for THIS scene (literal operands, no loops); debug flag 8 or RT_MI355_JIT=0 keeps
     // the generic kernel, debug flag 16 or RT_MI355_JIT=2 specialises at the first render (A/B and parity tests); an unavailable hiprtc is not an error, the generic kernel renders the same image
+    // Which form of the bounce loop (LDS-resident scenes).  Default: per-lane regeneration (path_body), the faster one on every
+    // configuration measured.  The queue form (path_queue_body: workgroup-level ray-queue compaction through
+    // LDS, fixed-point sums) is selected by RT_MI355_PATH=q or debug flag 256, unless something it cannot do is asked for:
+    // per-pixel ray counts (debug flag 4), negative or huge material colours (its sums are unsigned 32.32 fixed point).
+    {
+        const char* pk = getenv("RT_MI355_PATH");
+        bool ok = ((pk && pk[0] == 'q') || (c->debug_flags & 256)) && !noalloc && !accel && !(c->debug_flags & (2 | 4)) && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES;
+        for (int m = 0; ok && m < scene->n_materials; ++m)
+            for (int k = 0; k < 3; ++k) ok = ok && scene->materials[m].albedo[k] >= 0.0f && scene->materials[m].albedo[k] < 1e9f;
+        A.queue = ok ? 1 : 0;
+    }
     hipFunction_t jit = nullptr;
     const char* jit_env = getenv("RT_MI355_JIT");
     c->jit_note.clear();
     if (!noalloc && !accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
-        jit = jit_path_kernel(p->variant, H.slots, H.sruns, c->jit_note);
+        jit = jit_path_kernel(p->variant, H.slots, H.sruns, p->t_min, p->t_max, A.queue != 0, c->jit_note);
     if (noalloc) c->jit_note = "allocation-free entry point: generic kernel";
     if ((rc = begin_timed(c, st, counters))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
     c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));
@@ -706,7 +717,7 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
     if (p->shadow_samples > 0 && !(c->debug_flags & 8) && !(jit_env && jit_env[0] == '0') &&
         jit_wanted(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, (double)width * height * p->shadow_samples * (scene->n_lights > 0 ? scene->n_lights : 1),
                    (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
-        jit = jit_path_kernel(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, c->jit_note);
+        jit = jit_path_kernel(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, 0.01f, 1000.0f, false, c->jit_note);
     c->last_whitted_kernel = jit ? 2 : 1;
     if ((rc = begin_timed(c, st))) return rc;      // after a possible compile
     launch_whitted(p->shadow_samples > 0, D, A, (float4*)d_color, c->d_counters, st, jit);
@@ -776,10 +787,10 @@ int32_t rt_debug_last_whitted_kernel(const rt_ctx* c) { return c ? c->last_whitt
 // variant 3 / 4: the path kernels; 2: the 02 kernel (a Whitted scene)
 int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, int32_t cap) {
     HostScene H;
-    int rc = compile_scene(nullptr, scene, variant == RT_JIT_WHITTED_SOFT ? 0 : variant, H);
+    int rc = compile_scene(nullptr, scene, (variant & 7) == RT_JIT_WHITTED_SOFT ? 0 : (variant & 7), H);
     if (rc) return rc;
     std::string n;
-    hipFunction_t fn = jit_path_kernel(variant, H.slots, H.sruns, n);
+    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, (variant & 7) == 3 ? 0.001f : 0.01f, 1000.0f, (variant & 8) != 0, n);
     if (note && cap > 0) { strncpy(note, n.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
     return fn ? 1 : 0;
 }

@@ -22,6 +22,7 @@ struct PathArgs {
     int jitter;                     // spp > 1 (03 Main.cpp:331)
     int regen_threshold;            // idle lanes per wave that trigger a regeneration pass
     int debug_flags;                // bit 1 (2): no LDS staging (A/B switch); bit 2 (4): accumulator w = rays of the pixel
+    int queue;                      // LDS-resident scenes: the queue form of the bounce loop (path_queue_body) instead of per-lane regeneration
     uint32_t seed;
     float t_min, t_min_pos, t_max;  // t_min_pos = max(t_min, smallest positive float): "t > 0 && t >= tMin" in one compare
     float inv_w2, inv_h2, kx, ky;   // 2/w, 2/h, tan(fov/2)*w/h, tan(fov/2)

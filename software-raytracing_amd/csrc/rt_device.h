@@ -287,6 +287,18 @@ __device__ __forceinline__ uint32_t closest_hit_slots(const SceneMem<LDS> M, con
     return best;
 }
 
+// Closest-hit bookkeeping on unsigned keys (the scene-specialised kernels, rt_jit.hip): if (k <= ck) { ck = k; best = K; }.
+// Written as a subtraction whose borrow IS the compare (v_sub_co_u32, a full-rate VOP2, instead of a half-rate v_cmp) and two
+// selects through VCC; the difference itself is not needed, the empty asm only keeps the compiler from folding the
+// subtraction back into a compare.  "<=": among equal distances the LAST element wins, as in the reference's list walk.
+__device__ __forceinline__ void key_take(uint32_t& ck, uint32_t& best, uint32_t k, uint32_t K) {
+    uint32_t diff;
+    const bool further = __builtin_usub_overflow(ck, k, &diff);      // k > ck
+    asm volatile("" ::"v"(diff));
+    ck = further ? ck : k;
+    best = further ? best : K;
+}
+
 // wave64 sum of a per-lane counter, then one atomic per wave
 __device__ __forceinline__ void wave_add_u64(unsigned long long* dst, unsigned int v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -46,6 +46,28 @@ std::string lit(float v) {   // exact: hexadecimal floating literal
 }
 std::string v3(const float4& g) { return "F3(" + lit(g.x) + ", " + lit(g.y) + ", " + lit(g.z) + ")"; }
 
+
+// Literal-coefficient sums with the terms whose coefficient is exactly 0 left out: in the generic loops they are multiplied
+// out (x*0 = +-0, which changes no finite sum; only an infinite or NaN x would differ, and such a t is rejected by its key /
+// range test anyway), here they cost nothing.  dot3: a.x*v.x + a.y*v.y + a.z*v.z in the operation order of dot() (rt_device.h):
+// fmaf(a.z, v.z, fmaf(a.y, v.y, a.x * v.x)).  affine3: fmaf(a.z, v.z, fmaf(a.y, v.y, fmaf(a.x, v.x, w))).
+std::string dot3(const float4& a, const char* v) {
+    std::string e;
+    const float c[3] = {a.x, a.y, a.z}; const char* n[3] = {".x", ".y", ".z"};
+    for (int k = 0; k < 3; ++k) {
+        if (c[k] == 0.0f) continue;
+        const std::string term = std::string(v) + n[k];
+        e = e.empty() ? "(" + lit(c[k]) + " * " + term + ")" : "fmaf(" + lit(c[k]) + ", " + term + ", " + e + ")";
+    }
+    return e.empty() ? "0.0f" : e;
+}
+std::string affine3(const float4& a, const char* v) {
+    std::string e = lit(a.w);
+    const float c[3] = {a.x, a.y, a.z}; const char* n[3] = {".x", ".y", ".z"};
+    for (int k = 0; k < 3; ++k) if (c[k] != 0.0f) e = "fmaf(" + lit(c[k]) + ", " + std::string(v) + n[k] + ", " + e + ")";
+    return e;
+}
+
 // One block per primitive; K = byte offset of its slot in the slot section + SLOT_BYTES (0 stays "no hit").
 std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<int4>& sruns) {
     std::string s;
@@ -67,12 +89,12 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
                 const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
                 s += "    { float t = (" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + "; bool hit = (t >= tminp) & (t <= closest); " + take;
             } else if (run.x == PRIM_PLANE) {
-                s += "    { float t = (" + lit(g[0].w) + " - dot(" + v3(g[0]) + ", o)) * rcp_fast(dot(" + v3(g[0]) + ", d)); bool hit = (t >= tminp) & (t <= closest); " + take;
+                s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); bool hit = (t >= tminp) & (t <= closest); " + take;
             } else {   // rectangle / triangle: wide slot, G1..G3 behind the shading records
                 const float4 &g1 = g[4], &g2 = g[5], &g3 = g[6];
-                s += "    { float t = (" + lit(g[0].w) + " - dot(" + v3(g[0]) + ", o)) * rcp_fast(dot(" + v3(g[0]) + ", d)); f3 p = madd(d, t, o);\n";
-                s += "      float x = fmaf(" + lit(g1.z) + ", p.z, fmaf(" + lit(g1.y) + ", p.y, fmaf(" + lit(g1.x) + ", p.x, " + lit(g1.w) + ")));\n";
-                s += "      float y = fmaf(" + lit(g2.z) + ", p.z, fmaf(" + lit(g2.y) + ", p.y, fmaf(" + lit(g2.x) + ", p.x, " + lit(g2.w) + ")));\n";
+                s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); f3 p = madd(d, t, o);\n";
+                s += "      float x = " + affine3(g1, "p") + ";\n";
+                s += "      float y = " + affine3(g2, "p") + ";\n";
                 if (run.x == PRIM_RECT) s += "      bool in = (fabsf(x) <= " + lit(g3.x) + ") & (fabsf(y) <= " + lit(g3.y) + ");\n";
                 else                    s += "      bool in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);\n";
                 s += "      bool hit = (t >= tminp) & (t <= closest) & in; " + take;
@@ -81,12 +103,16 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
         }
     }
     s += "    t_out = closest;\n    return best;\n}\n";
+    return s;
+}
+std::string gen_any_hit(const std::vector<float4>& slots, const std::vector<int4>& sruns) {
+    std::string s;
+    size_t q = 0;
     // The same tests against a FIXED tMax, OR-ed (02's shadow samples): "something occludes" without the chain through
     // 'closest'.  Equivalent to closest_hit_jit(...) != 0: a test that fails there only because an earlier element was closer
     // changes nothing (that element occludes), and the sphere rule "origin inside, far root beyond tMax" occludes in both.
     s += "__device__ __forceinline__ bool any_hit_jit(f3 o, f3 d, float tmin, float tminp, float tmax) {\n";
     s += "    bool occ = false;\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d; (void)tmin; (void)tminp;\n";
-    q = 0;
     for (const int4& run : sruns) {
         for (int i = 0; i < run.z; ++i) {
             const float4* g = &slots[q];
@@ -99,12 +125,12 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
                 const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
                 s += "    { float t = (" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + "; occ |= (t >= tminp) & (t <= tmax); }\n";
             } else if (run.x == PRIM_PLANE) {
-                s += "    { float t = (" + lit(g[0].w) + " - dot(" + v3(g[0]) + ", o)) * rcp_fast(dot(" + v3(g[0]) + ", d)); occ |= (t >= tminp) & (t <= tmax); }\n";
+                s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); occ |= (t >= tminp) & (t <= tmax); }\n";
             } else {
                 const float4 &g1 = g[4], &g2 = g[5], &g3 = g[6];
-                s += "    { float t = (" + lit(g[0].w) + " - dot(" + v3(g[0]) + ", o)) * rcp_fast(dot(" + v3(g[0]) + ", d)); f3 p = madd(d, t, o);\n";
-                s += "      float x = fmaf(" + lit(g1.z) + ", p.z, fmaf(" + lit(g1.y) + ", p.y, fmaf(" + lit(g1.x) + ", p.x, " + lit(g1.w) + ")));\n";
-                s += "      float y = fmaf(" + lit(g2.z) + ", p.z, fmaf(" + lit(g2.y) + ", p.y, fmaf(" + lit(g2.x) + ", p.x, " + lit(g2.w) + ")));\n";
+                s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); f3 p = madd(d, t, o);\n";
+                s += "      float x = " + affine3(g1, "p") + ";\n";
+                s += "      float y = " + affine3(g2, "p") + ";\n";
                 if (run.x == PRIM_RECT) s += "      bool in = (fabsf(x) <= " + lit(g3.x) + ") & (fabsf(y) <= " + lit(g3.y) + ");\n";
                 else                    s += "      bool in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);\n";
                 s += "      occ |= (t >= tminp) & (t <= tmax) & in; }\n";
@@ -113,6 +139,106 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
         }
     }
     s += "    return occ;\n}\n} // namespace rt\n";
+    return s;
+}
+
+
+// ---- generation 2 of the generated scene query ("key" form) ------------------------------------------------------------
+// What the first generation spent most of its non-arithmetic instructions on is the bookkeeping per primitive: two float
+// compares (t >= tMin, t <= closest; 4.6 issue cycles each on gfx950, twice a VOP2), a scalar AND and two selects.  Here
+// the distance is carried as an unsigned KEY = bits(t) - bits(tMin): for t >= tMin (both positive floats) the key is a small
+// number that orders like t; for t < tMin, negative t and NaN the subtraction wraps or the sign bit makes the key larger
+// than any valid one - so ONE unsigned compare "key <= closest key" is the whole range test, exactly (no rounding: the
+// winner's t is key + bits(tMin), bit for bit what the loops of closest_hit_runs compute), and "<=" keeps the reference's
+// "last element wins ties".  tMin/tMax are literals (they are part of the generated source, hence of the cache key).
+// A sphere's two roots t1 <= t2 become k = min(k1, k2): k1 when t1 >= tMin, else k2 (k1 is then huge) - the reference's
+// "a root below tMin is replaced" (Common/Ray.hpp:127-128).  Its rule "origin inside, far root beyond tMax: hit AT tMax"
+// (:129-134) needs extra compares and is generated only for a sphere whose ball another primitive reaches into (or whose
+// diameter exceeds tMax): only then can something be hit before the ray leaves the sphere.
+struct Jit2 { uint32_t C, ck0, vmax; };
+uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+std::string hex(uint32_t u) { char b[32]; snprintf(b, sizeof b, "0x%08xU", u); return b; }
+
+// true when, for a ray that starts inside sphere 'self' (slot index q0), nothing else can be hit before it leaves the sphere
+bool sphere_interior_is_empty(const std::vector<float4>& slots, const std::vector<int4>& sruns, size_t q0, float tmin, float tmax) {
+    const float4 S = slots[q0];
+    const double r = std::sqrt((double)S.w), slack = r * 1e-4;
+    if (!(2.0 * r + tmin < tmax)) return false;
+    size_t q = 0;
+    for (const int4& run : sruns) {
+        for (int i = 0; i < run.z; ++i) {
+            const float4* g = &slots[q];
+            const size_t step = (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
+            if (q != q0) {
+                double dist;      // a lower bound of the distance from the sphere's centre to the other primitive's surface
+                if (run.x == PRIM_SPHERE) {
+                    const double dx = g[0].x - S.x, dy = g[0].y - S.y, dz = g[0].z - S.z;
+                    dist = std::fabs(std::sqrt(dx * dx + dy * dy + dz * dz) - std::sqrt((double)g[0].w));
+                } else if (run.x >= PRIM_AAPLANE_X) {
+                    const double c = run.x == PRIM_AAPLANE_X ? S.x : run.x == PRIM_AAPLANE_Y ? S.y : S.z;
+                    dist = std::fabs(c - g[0].x);
+                } else if (run.x == PRIM_PLANE) {
+                    const double nl = std::sqrt((double)g[0].x * g[0].x + (double)g[0].y * g[0].y + (double)g[0].z * g[0].z);
+                    dist = nl > 0 ? std::fabs((double)g[0].x * S.x + (double)g[0].y * S.y + (double)g[0].z * S.z - g[0].w) / nl : 0.0;
+                } else {          // rectangle / triangle: its bounding sphere (last float4 of the wide slot)
+                    const float4 b = g[7];
+                    const double dx = b.x - S.x, dy = b.y - S.y, dz = b.z - S.z;
+                    dist = std::isfinite(b.w) ? std::sqrt(dx * dx + dy * dy + dz * dz) - std::sqrt((double)b.w) : 0.0;
+                }
+                if (!(dist >= r - slack)) return false;
+            }
+            q += step;
+        }
+    }
+    return true;
+}
+
+std::string gen_closest_hit_v2(const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax) {
+    const float tminp = tmin > 0.0f ? tmin : 1.401298464e-45f;
+    Jit2 J{fbits(tminp), fbits(tmax) - fbits(tminp), 0x7f800000U - fbits(tminp)};
+    const std::string C = hex(J.C);
+    std::string s;
+    s += "namespace rt {\n__device__ __forceinline__ uint32_t closest_hit_jit(f3 o, f3 d, float, float, float, float& t_out) {\n";
+    s += "    uint32_t best = 0U, ck = " + hex(J.ck0) + ";\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d;\n";
+    auto take = [](const std::string& K) { return " key_take(ck, best, k, " + K + "); }\n"; };
+    size_t q = 0;
+    const char* skip = getenv("RT_MI355_JIT_SKIP");      // timing experiments only: leave a primitive type out of the generated query (wrong images)
+    for (const int4& run : sruns) {
+        for (int i = 0; i < run.z; ++i) {
+            const float4* g = &slots[q];
+            const std::string K = std::to_string(q * 16 + SLOT_BYTES) + "U";
+            if (skip && ((run.x == PRIM_SPHERE && strchr(skip, 's')) || (run.x >= PRIM_AAPLANE_X && strchr(skip, 'a')) || ((run.x == PRIM_RECT || run.x == PRIM_TRI) && strchr(skip, 'r')))) {
+                q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4; continue; }
+            if (run.x == PRIM_SPHERE) {
+                s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
+                s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
+                s += "      float s = sqrt_fast(fmaf(b, b, -c));\n";
+                if (sphere_interior_is_empty(slots, sruns, q, tmin, tmax)) {
+                    s += "      float t1 = b - s; uint32_t k = __float_as_uint(t1 < " + lit(tmin) + " ? b + s : t1) - " + C + ";\n";
+                    s += "     " + take(K);
+                    q += 4; continue;
+                }
+                s += "      uint32_t k1 = __float_as_uint(b - s) - " + C + ", k2 = __float_as_uint(b + s) - " + C + "; uint32_t k = k1 < k2 ? k1 : k2;\n";
+                // the tMax rule: near root behind tMin, far root ahead (finite) but not accepted: the element wins, the distance stays
+                    s += "      bool a = k <= ck; bool w = a | ((k1 > " + hex(J.vmax) + ") & (k2 <= " + hex(J.vmax) + ")); ck = a ? k : ck; best = w ? " + K + " : best; }\n";
+            } else if (run.x >= PRIM_AAPLANE_X) {
+                const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
+                s += "    { uint32_t k = __float_as_uint((" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + ") - " + C + ";" + take(K);
+            } else if (run.x == PRIM_PLANE) {
+                s += "    { uint32_t k = __float_as_uint((" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + ")) - " + C + ";" + take(K);
+            } else {
+                const float4 &g1 = g[4], &g2 = g[5], &g3 = g[6];
+                s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); f3 p = madd(d, t, o);\n";
+                s += "      float x = " + affine3(g1, "p") + ";\n";
+                s += "      float y = " + affine3(g2, "p") + ";\n";
+                if (run.x == PRIM_RECT) s += "      bool in = (fabsf(x) <= " + lit(g3.x) + ") & (fabsf(y) <= " + lit(g3.y) + ");\n";
+                else                    s += "      bool in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);\n";
+                s += "      uint32_t k = in ? __float_as_uint(t) - " + C + " : 0xffffffffU;" + take(K);
+            }
+            q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
+        }
+    }
+    s += "    t_out = __uint_as_float(ck + " + C + ");\n    return best;\n}\n";
     return s;
 }
 
@@ -147,11 +273,24 @@ bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector
     return false;
 }
 
-hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, std::string& note) {
+hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, bool queue, std::string& note) {
     size_t n_prims = 0;
     for (const int4& r : sruns) n_prims += (size_t)r.z;
     if (n_prims == 0 || n_prims > RT_JIT_MAX_PRIMS) { note = "scene has " + std::to_string(n_prims) + " slots (specialised up to " + std::to_string(RT_JIT_MAX_PRIMS) + ")"; return nullptr; }
-    std::string src = std::string("#define RT_JIT_SCENE 1\ntypedef unsigned int uint32_t; typedef unsigned char uint8_t; typedef unsigned long long uint64_t; typedef unsigned long uintptr_t;\n") + kSrcArgs + "\n" + kSrcDevice + "\n" + gen_closest_hit(slots, sruns);
+    std::string defs;      // RT_MI355_JIT_DEFS=NAME[,NAME...]: extra #defines for the generated source (A/B switches of the device code)
+    if (const char* d = getenv("RT_MI355_JIT_DEFS")) {
+        std::string cur;
+        for (const char* p = d;; ++p) {
+            if (*p == ',' || *p == 0) { if (!cur.empty()) defs += "#define " + cur + " 1\n"; cur.clear(); if (!*p) break; }
+            else cur += *p;
+        }
+    }
+    std::string src = defs + std::string("#define RT_JIT_SCENE 1\ntypedef unsigned int uint32_t; typedef unsigned char uint8_t; typedef unsigned long long uint64_t; typedef unsigned long uintptr_t;\n") + kSrcArgs + "\n" + kSrcDevice + "\n";
+    // generation 1 (float compares) is the default: on MI355X it measured 2 % faster than generation 2 (unsigned keys) although
+    // the latter has the cheaper instruction mix on paper; RT_MI355_JIT_GEN=2 selects generation 2 (same image, bit for bit)
+    const char* gen_env = getenv("RT_MI355_JIT_GEN");
+    const bool gen2 = variant != RT_JIT_WHITTED_SOFT && gen_env && gen_env[0] == '2' && tmin >= 0.0f && tmax > tmin && std::isfinite(tmax);
+    src += (gen2 ? gen_closest_hit_v2(slots, sruns, tmin, tmax) : gen_closest_hit(slots, sruns)) + gen_any_hit(slots, sruns);
     const char* entry = variant == RT_JIT_WHITTED_SOFT ? "k_whitted_jit" : "k_path_jit";
     if (variant == RT_JIT_WHITTED_SOFT)   // 02: the generated query serves the shadow samples of whitted_body<true>
         src += std::string(kSrcStrict) + "\n" + kSrcWhitted +
@@ -160,7 +299,7 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     else
         src += std::string(kSrcPath) +
             "\nextern \"C\" __global__ __launch_bounds__(256) void k_path_jit(rt::DevScene SD, rt::PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
-            "    rt::path_body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
+            "    rt::path_" + std::string(queue ? "queue_" : "") + "body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
     int dev = 0; (void)hipGetDevice(&dev);
     const auto key = std::make_pair(dev, fnv1a(src));
     std::lock_guard<std::mutex> lock(g_mu);

@@ -22,15 +22,27 @@ __global__ __launch_bounds__(256) void k_path_tiled(DevScene SD, PathArgs A, flo
     path_tiled_body<VARIANT>(SD, A, out, counters);
 }
 
+// Queue form (rt_path_device.h): ray-queue compaction through LDS inside the workgroup.
+template <int VARIANT, bool LDS, bool EARLY = false>
+__global__ __launch_bounds__(256) void k_path_q(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    path_queue_body<VARIANT, LDS, EARLY>(SD, A, out, counters);
+}
+
 template <int VARIANT>
 static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 15) / 16), n_slices);
     size_t bytes = (size_t)S.total_f4 * sizeof(float4);
-    if (jit && bytes <= RT_LDS_SCENE_MAX_BYTES) {   // scene-specialised k_path<VARIANT, true> (rt_jit.hip)
+    const bool queue = A.queue && bytes <= RT_LDS_SCENE_MAX_BYTES;      // queue form: LDS-resident scenes
+    if (jit && bytes <= RT_LDS_SCENE_MAX_BYTES) {   // scene-specialised k_path<VARIANT, true> / k_path_q<VARIANT, true> (rt_jit.hip)
         DevScene s = S; PathArgs a = A;
         void* params[] = {&s, &a, &out, &counters};
-        if (hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)bytes, st, params, nullptr) == hipSuccess) return;
+        if (hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)(bytes + (queue ? RT_Q_WS_BYTES : 0)), st, params, nullptr) == hipSuccess) return;
         (void)hipGetLastError();   // could not launch the specialised kernel: the generic one below renders the same image
+    }
+    if (queue && !(A.debug_flags & 2)) {
+        if (S.slot_bytes > 64 * 64) hipLaunchKernelGGL((k_path_q<VARIANT, true, true>), grid, dim3(256), bytes + RT_Q_WS_BYTES, st, S, A, out, counters);
+        else                        hipLaunchKernelGGL((k_path_q<VARIANT, true>), grid, dim3(256), bytes + RT_Q_WS_BYTES, st, S, A, out, counters);
+        return;
     }
     if (A.debug_flags & 2)                   hipLaunchKernelGGL((k_path<VARIANT, false>), grid, dim3(256), 0, st, S, A, out, counters);   // A/B reference: scalar loads from the global blob
     else if (bytes <= RT_LDS_SCENE_MAX_BYTES && S.slot_bytes > 64 * 64)   // mid-size scene (beyond the specialised builds): LDS-resident, wave-level early-outs

@@ -206,6 +206,174 @@ __device__ __forceinline__ void path_body(const DevScene& SD, const PathArgs& A,
     wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
 }
 
+// =================================================================================================
+// Queue form of the bounce loop (K3/K4): a wavefront pipeline inside the workgroup, with ray-queue
+// compaction through LDS.
+//
+// path_body keeps a lane on its pixel: a lane whose path has ended idles until enough of its wave is
+// idle to pay for a regeneration pass, and that pass then runs with most of the wave masked off.
+// Here a workgroup (4 waves) owns a 16x16 pixel tile and a QUEUE of work items (pixel, sample) of it.
+// Every iteration the workgroup compacts its live paths: each wave ballots its live lanes, takes a base
+// from an LDS counter (one atomic per wave) and its live lanes write their 48-byte path state to slot
+// base + mbcnt(ballot) of an LDS exchange buffer; after the barrier thread i < n_live reads state i and
+// the threads behind them take the next 256 - n_live work items.  So every wave but (at most) one is
+// full when it runs the scene query and the shading code, the camera code runs in whole waves, and no
+// path state ever leaves the CU (12 KB of LDS per workgroup; HBM sees only the final sums).
+// Paths are no longer tied to lanes, so a finished path hands its radiance over through the same
+// mechanism: it appends (rgb, pixel) to a "finished" list (second counter, same buffer, filled from the
+// end), and the first n_finished threads add the entries to the tile's accumulators in LDS.  Those are
+// 32.32 FIXED-POINT sums (ds_add_u64): integer addition is order-independent, so the image does not
+// depend on which wave got which base - reproducible bit for bit, run to run, like the rest.
+// (Radiance contributions are therefore taken as >= 0 and < 2^32; resolution 2^-32.)
+// Same RNG keys (pixel, sample), same camera arithmetic, same query and shading code as path_body: the
+// paths are identical, only the rounding of the per-pixel sum differs (fixed point vs running float).
+// =================================================================================================
+#define RT_Q_XCH_BYTES (256 * 48)
+#define RT_Q_WS_BYTES (RT_Q_XCH_BYTES + 256 * 3 * 8 + 256 * 8 + 64)      /* exchange + accumulators + pixel table + counters */
+template <int VARIANT, bool LDS, bool EARLY = false>
+__device__ __forceinline__ void path_queue_body(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    extern __shared__ float4 smem[];
+    const char* base = reinterpret_cast<const char*>(SD.blob);
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t ws_off = 0U;                       // the workspace sits behind the staged blob
+    if (LDS) {
+        for (int i = tid; i < SD.total_f4; i += 256) smem[i] = SD.blob[i];
+        base = reinterpret_cast<const char*>(smem);
+        ws_off = (uint32_t)SD.total_f4 * 16U;
+    }
+    char* const ws = reinterpret_cast<char*>(smem) + ws_off;
+    float4* const xch = reinterpret_cast<float4*>(ws);                                        // 256 x 3 float4: live states from the front ...
+    float4* const fin = reinterpret_cast<float4*>(ws + RT_Q_XCH_BYTES) - 1;                   // ... finished (rgb, pixel) entries from the back: fin[-k]
+    unsigned long long* const acc = reinterpret_cast<unsigned long long*>(ws + RT_Q_XCH_BYTES);   // 256 x 3 fixed-point sums
+    uint2* const pixtab = reinterpret_cast<uint2*>(ws + RT_Q_XCH_BYTES + 256 * 3 * 8);        // per tile pixel: {RNG pixel key, pixel index or ~0}
+    uint32_t* const cnt = reinterpret_cast<uint32_t*>(ws + RT_Q_XCH_BYTES + 256 * 3 * 8 + 256 * 8);   // [2 phases][live, finished]
+    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
+    const SceneMem<LDS> M{base};
+    const uint32_t slots0 = M.at((uint32_t)SD.off_slots * 16U), mats0 = M.at(0U);
+
+    const int tiles_x = (A.width + 15) >> 4;
+    const int tx16 = (blockIdx.x % tiles_x) * 16, ty16 = (blockIdx.x / tiles_x) * 16;
+    const int slice = blockIdx.y;
+    const int s_first = A.sample_begin + slice * A.slice_len;
+    const int s_end = min(s_first + A.slice_len, A.sample_end);
+    const int n_items = 256 * max(s_end - s_first, 0);
+    {   // this thread's own pixel of the tile: table entry and zeroed accumulators
+        const int px = tx16 + (tid & 15), py = ty16 + (tid >> 4);
+        const bool inside = px < A.width && py < A.height;
+        const uint32_t pixel = (uint32_t)(py * A.width + px);
+        pixtab[tid] = make_uint2(rng_pixel_key(A.seed, pixel), inside ? pixel : 0xFFFFFFFFU);
+        acc[3 * tid] = 0ULL; acc[3 * tid + 1] = 0ULL; acc[3 * tid + 2] = 0ULL;
+        if (tid < 4) cnt[tid] = 0U;
+    }
+    PathLane L = lane_init(0);
+    uint32_t pl = 0U;                           // tile pixel (0..255) of the lane's current path
+    int item_base = 0, phase = 0;
+    bool finished = false;                      // the lane's path ended in the last iteration and L.acc holds its radiance
+    for (;;) {
+        __syncthreads();                        // the exchange buffer is free (everyone has read the previous round), the counters of this phase are zero
+        // ---- compaction: live states to the front of the exchange buffer, finished paths' radiance to its back
+        const unsigned long long m_live = __builtin_amdgcn_ballot_w64(L.alive), m_fin = __builtin_amdgcn_ballot_w64(finished);
+        uint32_t b_live = 0U, b_fin = 0U;
+        if (lane == 0) {
+            b_live = atomicAdd(&cnt[2 * phase], (uint32_t)__popcll(m_live));
+            if (m_fin) b_fin = atomicAdd(&cnt[2 * phase + 1], (uint32_t)__popcll(m_fin));
+        }
+        b_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_live); b_fin = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_fin);
+        if (L.alive) {
+            const uint32_t r = b_live + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_live, 0U));
+            float4* dst = xch + 3U * r;
+            dst[0] = make_float4(L.o.x, L.o.y, L.o.z, L.d.x);
+            dst[1] = make_float4(L.d.y, L.d.z, L.thr.x, L.thr.y);
+            dst[2] = make_float4(L.thr.z, __uint_as_float(L.rkey), __int_as_float(L.depth), __uint_as_float(pl));
+        } else if (finished) {
+            const uint32_t r = b_fin + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_fin >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_fin, 0U));
+            fin[-(int)r] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(pl));
+        }
+        __syncthreads();                        // all states and entries are in place, the counters are final
+        const int n_live = (int)cnt[2 * phase], n_fin = (int)cnt[2 * phase + 1];
+        if (tid < 2) cnt[2 * (phase ^ 1) + tid] = 0U;       // the other phase's counters: nobody touches them before the next barrier
+        phase ^= 1;
+        if (n_live == 0 && item_base >= n_items) {          // workgroup-uniform: nothing in flight, nothing left to start
+            if (tid < n_fin) {                              // the last finished paths
+                const float4 e = fin[-tid];
+                const uint32_t q = __float_as_uint(e.w);
+                atomicAdd(&acc[3 * q], ((unsigned long long)(uint32_t)e.x << 32) | (uint32_t)(__builtin_amdgcn_fractf(e.x) * 4294967296.0f));
+                atomicAdd(&acc[3 * q + 1], ((unsigned long long)(uint32_t)e.y << 32) | (uint32_t)(__builtin_amdgcn_fractf(e.y) * 4294967296.0f));
+                atomicAdd(&acc[3 * q + 2], ((unsigned long long)(uint32_t)e.z << 32) | (uint32_t)(__builtin_amdgcn_fractf(e.z) * 4294967296.0f));
+            }
+            break;
+        }
+        float4 fe = make_float4(0, 0, 0, 0);
+        if (tid < n_fin) fe = fin[-tid];                    // read before anything else: the slot may be overwritten next round only
+        // ---- every thread takes a path: the first n_live an existing one, the rest new work items (camera code in whole waves)
+        if (tid < n_live) {
+            const float4 a = xch[3 * tid], b = xch[3 * tid + 1], c = xch[3 * tid + 2];
+            L.o = F3(a.x, a.y, a.z); L.d = F3(a.w, b.x, b.y); L.thr = F3(b.z, b.w, c.x);
+            L.rkey = __float_as_uint(c.y); L.depth = __float_as_int(c.z); pl = __float_as_uint(c.w);
+            L.alive = true;
+        } else {
+            const int item = item_base + (tid - n_live);
+            L.alive = false;
+            if (item < n_items) {
+                pl = (uint32_t)item & 255U;
+                const uint2 pt = pixtab[pl];
+                if (pt.y != 0xFFFFFFFFU) {      // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369); same arithmetic as regenerate()
+                    const int px = tx16 + (int)(pl & 15U), py = ty16 + (int)(pl >> 4);
+                    L.skey = rng_sample_key(pt.x, (uint32_t)(s_first + (item >> 8)));
+                    L.rkey = L.skey + 5U * 0x9E3779B9U;
+                    float bx = 0.5f, by = 0.5f;
+                    if (A.jitter) rng_pair(L.skey, 0U, bx, by);
+                    float x = fmaf((float)px + bx, A.inv_w2, -1.0f) * A.kx;
+                    float y = -fmaf((float)py + by, A.inv_h2, -1.0f) * A.ky;
+                    f3 v = F3(x, y, -1.0f);
+                    const f3 rv = F3(dot(F3(A.r[0], A.r[1], A.r[2]), v), dot(F3(A.r[3], A.r[4], A.r[5]), v), dot(F3(A.r[6], A.r[7], A.r[8]), v));
+                    L.d = rv * rsq_fast(dot(rv, rv));
+                    L.o = F3(A.px, A.py, A.pz);
+                    L.thr = F3(1, 1, 1);
+                    L.depth = 0;
+                    L.alive = true;
+                }
+            }
+        }
+        item_base += 256 - n_live;
+        L.acc = F3(0, 0, 0);
+        // ---- the finished list: its first n_fin entries go to the tile's fixed-point sums (mostly one wave's work)
+        if (tid < n_fin) {
+            const uint32_t q = __float_as_uint(fe.w);
+            atomicAdd(&acc[3 * q], ((unsigned long long)(uint32_t)fe.x << 32) | (uint32_t)(__builtin_amdgcn_fractf(fe.x) * 4294967296.0f));
+            atomicAdd(&acc[3 * q + 1], ((unsigned long long)(uint32_t)fe.y << 32) | (uint32_t)(__builtin_amdgcn_fractf(fe.y) * 4294967296.0f));
+            atomicAdd(&acc[3 * q + 2], ((unsigned long long)(uint32_t)fe.z << 32) | (uint32_t)(__builtin_amdgcn_fractf(fe.z) * 4294967296.0f));
+        }
+        // ---- TraceTay: one scene query and one bounce for every live lane
+        finished = false;
+        if (L.alive) {
+            ++L.rays;
+            float t;
+#ifdef RT_JIT_SCENE
+            const uint32_t k = closest_hit_jit(L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+            const uint32_t hit = k + (slots0 - SLOT_BYTES);
+            const bool miss = k == 0U;
+            (void)runs;
+#else
+            uint32_t hit = closest_hit_slots<LDS, EARLY>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+            const bool miss = hit == 0U;
+#endif
+            shade<VARIANT, LDS>(M, A, mats0, miss, hit, t, L);
+            finished = !L.alive && (L.acc.x != 0.0f || L.acc.y != 0.0f || L.acc.z != 0.0f);     // black paths have nothing to hand over
+        }
+    }
+    __syncthreads();
+    {   // thread i writes tile pixel i: fixed point -> float (sum rgb, samples of this slice)
+        const uint2 pt = pixtab[tid];
+        if (pt.y != 0xFFFFFFFFU) {
+            const unsigned long long r = acc[3 * tid], g = acc[3 * tid + 1], b = acc[3 * tid + 2];
+            auto tof = [](unsigned long long v) { return (float)((double)v * (1.0 / 4294967296.0)); };
+            out[(size_t)slice * A.width * A.height + pt.y] = make_float4(tof(r), tof(g), tof(b), (float)(n_items >> 8));
+        }
+    }
+    wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
+}
+
 // Large scenes (blob > 48 KB): the slot section is walked in pieces of <= RT_TILE_BYTES that the block's four waves
 // stage through LDS together (one global read per block instead of one per wave, and VGPR operands for the tests), so
 // the bounce loop runs in lockstep per BLOCK: regenerate per wave, then every chunk between two barriers, then shade.

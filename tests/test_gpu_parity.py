@@ -296,6 +296,67 @@ def test_scene_specialised_kernel_matches_generic(ctx, which):
     assert ctx.last_path_kernel()[0] == 2 and np.array_equal(a["rgb"], c["rgb"])
 
 
+@pytest.mark.parametrize("which", ["04", "03", "mixed", "mid"])
+def test_queue_form_renders_the_same_paths(ctx, which, monkeypatch):
+    """The queue form of the bounce loop (path_queue_body: workgroup-level ray-queue compaction through LDS, selected by
+    RT_MI355_PATH=q) traces the SAME paths as the default per-lane regeneration loop - identical ray counts - and differs only in
+    how a pixel's samples are summed (order-independent 32.32 fixed point instead of a running float): images agree to 1e-6
+    relative, and two runs of the queue form agree bit for bit (no dependence on which wave took which queue slot)."""
+    if which == "04":
+        (s, cam, prm), (w, h) = scenes.scene04(24, seed=5), (200, 136)       # sizes that leave tiles partly outside the frame
+    elif which == "03":
+        (s, cam, prm), (w, h) = scenes.scene03(24, seed=5, readme_variant=True), (200, 136)
+    elif which == "mixed":
+        s = scenes.Scene()
+        white = s.diffuse((0.7, 0.7, 0.7)); metal = s.metal((0.9, 0.8, 0.7), 0.1); glass = s.dielectric(0.7); lm = s.light_material((8, 7, 6))
+        s.plane(white, (0, -3, 0), (0, 1, 0)); s.plane(white, (0, 0, -12), (0.2, 0.1, 1.0))
+        s.triangle(metal, (-6, -3, -9), (-1, -3, -11), (-4, 3, -10)); s.box(white, (3, -2, -7), (2, 2, 2), (0, 30, 10))
+        s.sphere(glass, (0, -1.5, -6), 1.5); s.sphere(glass, (0, -1.5, -6), 1.2, flip=True); s.sphere(-1, (3, 0.5, -7), 0.5)
+        s.rect(lm, (0, 5, -6), (4, 3), (70, 20, 0))
+        cam = scenes.camera(75.0, (0.5, 0.2, 2.0), (-5, 8, 3)); prm = scenes.path_params(abi.RT_PATH_LIGHTS, 16, max_depth=5, seed=4)
+        w, h = 160, 120
+    else:   # 184 primitives: beyond the scene-specialised builds, the generic LDS-resident kernels
+        (s, cam, prm), (w, h) = scenes.scene_stress(n_spheres=150, grid=4, spp=8, seed=7), (160, 90)
+    res = {}
+    for form in ("r", "q", "q2"):
+        monkeypatch.setenv("RT_MI355_PATH", form[0])
+        for flags, name in ((8, "generic"), (16, "specialised")):
+            if which == "mid" and flags == 16:
+                continue
+            ctx.set_debug_flags(flags)
+            try:
+                res[(form, name)] = ctx.render_path(s, cam, prm, w, h)
+            finally:
+                ctx.set_debug_flags(0)
+    for name in ("generic", "specialised"):
+        if ("r", name) not in res:
+            continue
+        r, q, q2 = res[("r", name)], res[("q", name)], res[("q2", name)]
+        assert r["rays"] == q["rays"] == q2["rays"] and r["samples"] == q["samples"]
+        assert np.array_equal(q["rgb"], q2["rgb"]) and np.array_equal(q["bgra"], q2["bgra"])
+        assert np.allclose(q["rgb"], r["rgb"], rtol=1e-6, atol=1e-7)
+        assert (np.abs(q["bgra"].astype(int) - r["bgra"].astype(int)) <= 1).all()
+    if which != "mid":
+        assert np.array_equal(res[("q", "generic")]["rgb"], res[("q", "specialised")]["rgb"])
+
+
+@pytest.mark.parametrize("which", ["04", "03r"])
+def test_key_form_of_the_generated_query_is_bit_identical(ctx, which, monkeypatch):
+    """RT_MI355_JIT_GEN=2: the generated scene query carries distances as unsigned keys bits(t) - bits(tMin) (one unsigned
+    compare = the whole range test).  Exact by construction: same image, bit for bit, as generation 1 and the generic loops."""
+    s, cam, prm = scenes.scene04(8, seed=5) if which == "04" else scenes.scene03(8, seed=5, readme_variant=True)
+    img = {}
+    for gen in ("1", "2"):
+        monkeypatch.setenv("RT_MI355_JIT_GEN", gen)
+        ctx.set_debug_flags(16)
+        try:
+            img[gen] = ctx.render_path(s, cam, prm, 160, 120)
+            assert ctx.last_path_kernel()[0] == 2
+        finally:
+            ctx.set_debug_flags(0)
+    assert img["1"]["rays"] == img["2"]["rays"] and np.array_equal(img["1"]["rgb"], img["2"]["rgb"])
+
+
 def test_specialisation_policy_and_cache_across_scenes(ctx):
     """Default policy: first render of a scene -> generic kernel, second -> specialised (compiled once, then cached);
     alternating scenes keep their own kernels and their own images."""

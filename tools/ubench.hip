@@ -123,6 +123,12 @@ KERNEL(k_min_i32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = th
 KERNEL(k_min3_u32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
 KERNEL(k_add3, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b))))
 
+KERNEL(k_sub_co, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_sub_co_u32_e32 %0, vcc, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a)) : "vcc"))
+KERNEL(k_subco_2cnd, unsigned x[CHAINS]; unsigned y[CHAINS]; for (int c = 0; c < CHAINS; ++c) { x[c] = threadIdx.x + c; y[c] = c; }, { unsigned t_; asm volatile("v_sub_co_u32_e32 %2, vcc, %0, %3\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %3, %0, vcc\n\tv_cndmask_b32_e32 %1, %4, %1, vcc" : "+v"(x[c]), "+v"(y[c]), "=&v"(t_) : "v"(__float_as_uint(a)), "v"(__float_as_uint(b)) : "vcc"); })
+KERNEL(k_cmp_nop_2cnd, float x[CHAINS]; float y[CHAINS]; for (int c = 0; c < CHAINS; ++c) { x[c] = threadIdx.x + c; y[c] = c; }, asm volatile("v_cmp_lt_f32 vcc, %0, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %1, %1, %2, vcc" : "+v"(x[c]), "+v"(y[c]) : "v"(a), "v"(b) : "vcc"))
+KERNEL(k_or_b32, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_or_b32 %0, %0, %1" : "+v"(x[c]) : "v"(__float_as_uint(a))))
+KERNEL(k_addc, unsigned x[CHAINS]; for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x + c, asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %1, vcc" : "+v"(x[c]) : "v"(__float_as_uint(a)) : "vcc"))
+
 template <typename K>
 void run(const char* name, K k, float* d, double ops_per_instr) {
     int blocks = 256 * 8;
@@ -160,6 +166,7 @@ int main() {
     run("v_fma neg mod", k_fma_neg, d, 2); run("v_mul_e64 neg", k_mul_e64neg, d, 1); run("v_max_e64 abs", k_max_abs, d, 1); run("v_cvt_f32_ubyte0", k_cvt_ubyte, d, 1);
     run("v_cmp_lt_u32_e64->s", k_cmp_lt_u32_s, d, 1); run("v_bfe_u32", k_bfe, d, 1); run("v_max_u32", k_max_u32, d, 1); run("v_min_i32", k_min_i32, d, 1); run("v_min3_u32", k_min3_u32, d, 1);
     run("v_add3_u32", k_add3, d, 1);
+    run("v_sub_co_u32", k_sub_co, d, 1); run("sub_co+nop+2cndmask", k_subco_2cnd, d, 3); run("cmp+nop+2cndmask", k_cmp_nop_2cnd, d, 3); run("v_or_b32", k_or_b32, d, 1); run("v_addc_co_u32", k_addc, d, 1);
     hipLaunchKernelGGL(k_clock, dim3(2048), dim3(256), 0, 0, d, 1.0001f, 0.5f); hipDeviceSynchronize();
     hipFree(d);
     return 0;
