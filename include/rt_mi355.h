@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2   /* 2: rt_stats.allreduce_ms, rt_create_multi */
 
 /* ---- return codes -------------------------------------------------------------------- */
 #define RT_OK               0
@@ -157,6 +157,8 @@ typedef struct rt_stats {
     uint64_t samples;       /* pixel-samples of the last render                              */
     double   kernel_ms;     /* HIP-event time of the tracing kernel(s) of the last render    */
     double   total_ms;      /* wall time of the last call incl. uploads and read-back        */
+    double   allreduce_ms;  /* device groups: GPU time of the sum of the per-GPU accumulators (else 0); for a
+                               group, rays/samples add up over its devices and kernel_ms is the slowest device's */
 } rt_stats;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -167,6 +169,15 @@ typedef struct rt_ctx rt_ctx;
  * Replaces nothing in the reference (it has no device); it is what the four Render wrappers
  * call once per process. */
 rt_ctx* rt_create(int32_t device_id);
+/* A context over several GPUs of one node (one process drives them all).  Replaces the reference's 8-thread split of 04
+ * Render (04 Main.cpp:399-420): rt_render_path on such a context cuts the frame's samples into n_devices contiguous ranges,
+ * device_ids[i] renders range i of EVERY pixel into its own accumulator (all devices side by side, one stream each), the
+ * accumulators are combined with ONE RCCL all-reduce(sum, float32) over xGMI (librccl is loaded at this call, with
+ * dlopen), and device_ids[0] resolves the frame.  The result does not depend on n_devices except for the order of the
+ * float additions.  A device id may be listed more than once (rehearsal of the group code on one GPU; the sums then go
+ * through copies to device_ids[0] instead of RCCL).  Whitted renders and the device-buffer entry points use
+ * device_ids[0] only.  Returns NULL on failure (rt_last_error(NULL)); rt_destroy frees the whole group. */
+rt_ctx* rt_create_multi(const int32_t* device_ids, int32_t n_devices);
 void    rt_destroy(rt_ctx* ctx);
 const char* rt_last_error(const rt_ctx* ctx);   /* ctx may be NULL for rt_create failures    */
 int32_t rt_get_stats(const rt_ctx* ctx, rt_stats* out);

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -138,6 +139,13 @@ struct rt_ctx {
     std::string err;
     int regen_threshold_override = -1;
     int debug_flags = 0;
+    // device group (rt_create_multi): this context renders on device_ids[0] and owns one child context per further entry;
+    // a path render is split into sample ranges over all of them and the accumulators are summed (see render_path_group)
+    std::vector<rt_ctx*> peers;
+    std::vector<hipEvent_t> peer_done;            // per peer, on its device: its accumulator is complete
+    hipEvent_t ar0 = nullptr, ar1 = nullptr;      // timing of the sum on this device's stream
+    void* rccl_lib = nullptr; std::vector<void*> comms;   // RCCL communicators, one per device of the group (all devices distinct)
+    DevBuf gather;                                // root-gather form: a peer's accumulator copied to this device
     int accel = 0;                                // RT_OPT_ACCEL: 0 brute force (the reference's algorithm), 1 BVH
     // what scene_buf holds: a render of the same scene (same bytes, variant, BVH or not, stream) skips compile, build and upload
     bool cache_valid = false; uint64_t cache_key = 0; hipStream_t cache_stream = nullptr;
@@ -489,6 +497,37 @@ int pick_slices(int width, int height, int n_samples) {
     return s < 1 ? 1 : s;
 }
 
+// ---- device group: RCCL bound at run time ------------------------------------------------------------------------------
+// librccl is loaded with dlopen when a group of DISTINCT devices is created, not linked: a process that also runs
+// torch.distributed already holds PyTorch's own copy of RCCL, and a single-GPU user needs none.  Signatures of rccl.h.
+struct Rccl {
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t st) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;      // rccl.h: ncclFloat32 = 7, ncclSum = 0
+bool rccl_bind(void* lib) {
+    auto sym = [&](const char* n) { return dlsym(lib, n); };
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    return g_rccl.CommInitAll && g_rccl.AllReduce && g_rccl.GroupStart && g_rccl.GroupEnd && g_rccl.CommDestroy && g_rccl.GetErrorString;
+}
+
+// Sample range [s0, s1) cut into n contiguous shares; share i (may be empty).  The reference's own split is by pixel ranges
+// over 8 threads (04 Main.cpp:399-420); sample ranges balance whatever the scene.
+void share_of(int s0, int s1, int i, int n, int& b, int& e) {
+    const long long len = s1 - s0;
+    b = s0 + (int)(len * i / n); e = s0 + (int)(len * (i + 1) / n);
+}
+
 } // namespace
 
 extern "C" {
@@ -530,7 +569,17 @@ rt_ctx* rt_create(int32_t device_id) {
 
 void rt_destroy(rt_ctx* c) {
     if (!c) return;
+    for (void* comm : c->comms) if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+    c->comms.clear();
+    for (size_t i = 0; i < c->peers.size(); ++i) {
+        if (c->peer_done[i]) { (void)hipSetDevice(c->peers[i]->device); (void)hipEventDestroy(c->peer_done[i]); }
+        rt_destroy(c->peers[i]);
+    }
+    c->peers.clear(); c->peer_done.clear();
     (void)hipSetDevice(c->device);
+    if (c->ar0) (void)hipEventDestroy(c->ar0);
+    if (c->ar1) (void)hipEventDestroy(c->ar1);
+    c->gather.release();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->scene_buf.release(); c->partial.release(); c->accum.release(); c->bgra.release(); c->rgb.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -543,6 +592,37 @@ void rt_destroy(rt_ctx* c) {
     if (c->h_stage_na) (void)hipHostFree(c->h_stage_na);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+rt_ctx* rt_create_multi(const int32_t* device_ids, int32_t n_devices) {
+    if (!device_ids || n_devices <= 0 || n_devices > RT_MAX_DEVICES) { g_create_error = "rt_create_multi: null list or device count outside [1, 64]"; return nullptr; }
+    rt_ctx* c = rt_create(device_ids[0]);
+    if (!c) return nullptr;
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i) for (int j = 0; j < i; ++j) distinct = distinct && device_ids[i] != device_ids[j];
+    for (int i = 1; i < n_devices; ++i) {
+        rt_ctx* p = rt_create(device_ids[i]);
+        if (!p) { rt_destroy(c); return nullptr; }      // g_create_error says which device and why
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { g_create_error = "rt_create_multi: hipEventCreate failed"; rt_destroy(p); rt_destroy(c); return nullptr; }
+        c->peers.push_back(p); c->peer_done.push_back(ev);
+    }
+    (void)hipSetDevice(c->device);
+    if (hipEventCreate(&c->ar0) != hipSuccess || hipEventCreate(&c->ar1) != hipSuccess) { g_create_error = "rt_create_multi: hipEventCreate failed"; rt_destroy(c); return nullptr; }
+    // Distinct devices: one RCCL communicator per device, a single process driving all of them (ncclCommInitAll); the per-GPU
+    // accumulators are then combined with ONE all-reduce over xGMI.  The same device listed twice (a one-GPU rehearsal of the
+    // group code) cannot form a communicator: the sums then go through the root-gather form (copy to device_ids[0], add).
+    if (distinct && n_devices > 1 && !(getenv("RT_MI355_NO_RCCL"))) {
+        c->rccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!c->rccl_lib) c->rccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!c->rccl_lib || !rccl_bind(c->rccl_lib)) { g_create_error = std::string("rt_create_multi: cannot load RCCL (librccl.so): ") + (dlerror() ? dlerror() : "missing symbols"); rt_destroy(c); return nullptr; }
+        c->comms.assign((size_t)n_devices, nullptr);
+        std::vector<int> devs(device_ids, device_ids + n_devices);
+        int r = g_rccl.CommInitAll(c->comms.data(), n_devices, devs.data());
+        if (r != 0) { g_create_error = std::string("rt_create_multi: ncclCommInitAll: ") + g_rccl.GetErrorString(r); c->comms.clear(); rt_destroy(c); return nullptr; }
+        (void)hipSetDevice(c->device);
+    }
+    return c;
 }
 
 const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
@@ -738,9 +818,83 @@ int32_t rt_resolve_device(rt_ctx* c, const float* d_accum, int32_t width, int32_
     return RT_OK;
 }
 
+// Path render on a device group: device i renders share i of the sample range into its own full-frame accumulator (all
+// devices enqueued before anything is waited for), then the accumulators are summed - one RCCL all-reduce over the group's
+// communicators (distinct devices), or copies to the first device added in a fixed order (root-gather form) - and the first
+// device resolves the frame.  d_accum_root: the first device's accumulator (c->accum), holding the sum on return.
+static int32_t path_accumulate_group(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* pp, int W, int Hh) {
+    const int n = 1 + (int)c->peers.size();
+    const size_t npx = (size_t)W * Hh, bytes = npx * sizeof(float4);
+    int s0 = pp->sample_begin, s1 = pp->sample_end;
+    if (s0 == 0 && s1 == 0) s1 = pp->spp;
+    if (pp->spp <= 0 || s0 < 0 || s1 < s0) return fail(c, RT_ERR_BAD_ARG, "bad spp / sample range");
+    int rc;
+    for (int i = 0; i < n; ++i) {                       // fan out
+        rt_ctx* d = i ? c->peers[i - 1] : c;
+        if ((rc = check_ctx(d))) return fail(c, rc, "device group: " + d->err);
+        d->debug_flags = c->debug_flags; d->accel = c->accel; d->regen_threshold_override = c->regen_threshold_override;
+        if (hipError_t e = d->accum.reserve(bytes)) return fail(c, RT_ERR_HIP, std::string("device group: accumulator: ") + hipGetErrorString(e));
+        rt_path_params q = *pp;
+        share_of(s0, s1, i, n, q.sample_begin, q.sample_end);
+        if (q.sample_end > q.sample_begin) {
+            if ((rc = rt_path_accumulate_device(d, scene, cam, &q, W, Hh, (float*)d->accum.p, nullptr))) return fail(c, rc, "device group: device " + std::to_string(d->device) + ": " + d->err);
+        } else {                                        // an empty share ((0,0) would mean "the whole frame"): zeros
+            HIPCHK(c, hipMemsetAsync(d->accum.p, 0, bytes, d->stream));
+            d->pending_samples = 0; d->timing_pending = false; d->stats = rt_stats{};
+        }
+        if (i) HIPCHK(c, hipEventRecord(c->peer_done[i - 1], d->stream));
+    }
+    if ((rc = check_ctx(c))) return rc;
+    HIPCHK(c, hipEventRecord(c->ar0, c->stream));
+    if (!c->comms.empty()) {                            // one all-reduce(sum, float32) of the per-GPU accumulators, in place
+        int r = g_rccl.GroupStart();
+        for (int i = 0; i < n && r == 0; ++i) {
+            rt_ctx* d = i ? c->peers[i - 1] : c;
+            (void)hipSetDevice(d->device);
+            r = g_rccl.AllReduce(d->accum.p, d->accum.p, npx * 4, kNcclFloat32, kNcclSum, c->comms[(size_t)i], d->stream);
+        }
+        const int r2 = g_rccl.GroupEnd();
+        (void)hipSetDevice(c->device);
+        if (r != 0 || r2 != 0) return fail(c, RT_ERR_HIP, std::string("device group: ncclAllReduce: ") + g_rccl.GetErrorString(r ? r : r2));
+    } else {                                            // root-gather form
+        for (int i = 1; i < n; ++i) {
+            rt_ctx* d = c->peers[i - 1];
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->peer_done[i - 1], 0));
+            const float4* src = (const float4*)d->accum.p;
+            if (d->device != c->device) {
+                HIPCHK(c, c->gather.reserve(bytes));
+                HIPCHK(c, hipMemcpyPeerAsync(c->gather.p, c->device, d->accum.p, d->device, bytes, c->stream));
+                src = (const float4*)c->gather.p;
+            }
+            launch_add_image((float4*)c->accum.p, src, (int)npx, c->stream);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ar1, c->stream));
+    return RT_OK;
+}
+// Collects the group's counters after the first device's stream has drained: rays and samples add up, the kernel time is
+// the slowest device's (they run side by side).
+static int32_t group_sync(rt_ctx* c) {
+    int rc;
+    uint64_t rays = c->stats.rays, srays = c->stats.shadow_rays, samples = c->stats.samples;
+    double kms = c->stats.kernel_ms;
+    for (rt_ctx* d : c->peers) {
+        if ((rc = rt_sync(d, nullptr))) return fail(c, rc, "device group: " + d->err);
+        rays += d->stats.rays; srays += d->stats.shadow_rays; samples += d->stats.samples;
+        kms = d->stats.kernel_ms > kms ? d->stats.kernel_ms : kms;
+    }
+    if ((rc = check_ctx(c))) return rc;
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ar0, c->ar1));
+    c->stats.rays = rays; c->stats.shadow_rays = srays; c->stats.samples = samples; c->stats.kernel_ms = kms; c->stats.allreduce_ms = ms;
+    return RT_OK;
+}
+
 static int32_t render_host(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_whitted_params* wp, const rt_path_params* pp, const rt_image* out) {
     auto t0 = std::chrono::steady_clock::now();
     int rc = check_ctx(c); if (rc) return rc;
+    const bool group = !wp && pp && !c->peers.empty();      // Whitted frames (one ray tree per pixel, < 1 ms) stay on the first device
     if (!out || out->width <= 0 || out->height <= 0 || (!out->bgra && !out->rgb)) return fail(c, RT_ERR_BAD_ARG, "image: null or non-positive size");
     int W = out->width, Hh = out->height;
     size_t npx = (size_t)W * Hh;
@@ -751,6 +905,7 @@ static int32_t render_host(rt_ctx* c, const rt_scene* scene, const rt_camera* ca
     if (out->rgb) HIPCHK(c, c->rgb.reserve(npx * 3 * sizeof(float)));
     float divisor = 1.0f; int gamma = 0;
     if (wp) rc = rt_whitted_device(c, scene, cam, wp, W, Hh, (float*)c->accum.p, nullptr);
+    else if (group) { rc = path_accumulate_group(c, scene, cam, pp, W, Hh); divisor = (float)pp->spp; gamma = 1; }
     else { rc = rt_path_accumulate_device(c, scene, cam, pp, W, Hh, (float*)c->accum.p, nullptr); divisor = pp ? (float)pp->spp : 1.0f; gamma = 1; }
     if (rc) return rc;
     rc = rt_resolve_device(c, (const float*)c->accum.p, W, Hh, divisor, gamma, out->bgra ? (uint8_t*)c->bgra.p : nullptr, stride,
@@ -758,7 +913,9 @@ static int32_t render_host(rt_ctx* c, const rt_scene* scene, const rt_camera* ca
     if (rc) return rc;
     if (out->bgra) HIPCHK(c, hipMemcpyAsync(out->bgra, c->bgra.p, (size_t)stride * Hh, hipMemcpyDeviceToHost, c->stream));
     if (out->rgb) HIPCHK(c, hipMemcpyAsync(out->rgb, c->rgb.p, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    c->stats.allreduce_ms = 0.0;
     if ((rc = rt_sync(c, nullptr))) return rc;
+    if (group && (rc = group_sync(c))) return rc;
     c->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
 }
@@ -846,6 +1003,12 @@ int32_t rt_debug_bvh_probe(const rt_scene* scene, int32_t variant, int32_t* out)
     if ((int)B.refs.size() != n_bounded || B.unbounded.size() + B.refs.size() != H.items.size()) ++bad;
     if (out) { out[0] = n_nodes; out[1] = (int)B.refs.size(); out[2] = (int)B.unbounded.size(); out[3] = B.depth; out[4] = (int)H.items.size(); }
     return bad;
+}
+// the device group's partition of a sample range (rt_create_multi); needs no GPU
+int32_t rt_debug_group_share(int32_t s0, int32_t s1, int32_t i, int32_t n, int32_t* b, int32_t* e) {
+    if (!b || !e || n <= 0 || i < 0 || i >= n || s1 < s0) return RT_ERR_BAD_ARG;
+    int bb, ee; share_of(s0, s1, i, n, bb, ee); *b = bb; *e = ee;
+    return RT_OK;
 }
 int32_t rt_debug_set_flags(rt_ctx* c, int32_t f) { if (!c) return RT_ERR_BAD_ARG; c->debug_flags = f; return RT_OK; }
 int32_t rt_debug_set_regen_threshold(rt_ctx* c, int32_t n) { if (!c) return RT_ERR_BAD_ARG; c->regen_threshold_override = n; return RT_OK; }

@@ -13,6 +13,7 @@ struct DevScene;
 void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit);
 // optional BVH walk (rt_bvh.h, rt_bvh_device.h)
 void launch_path_bvh(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st);
+void launch_add_image(float4* dst, const float4* src, int n_pixels, hipStream_t st);
 void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* out, hipStream_t st);
 // jit: scene-specialised 02 kernel (rt_jit.h) or nullptr
 void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st, hipFunction_t jit);

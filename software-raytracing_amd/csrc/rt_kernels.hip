@@ -78,6 +78,16 @@ __global__ __launch_bounds__(256) void k_sum_slices(const float4* __restrict__ p
     for (int s = 1; s < n_slices; ++s) { float4 b = part[(size_t)s * n_pixels + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     out[i] = a;
 }
+// dst += src (the root-gather form of the multi-device sum, rt_api.hip): fixed order, so deterministic
+__global__ __launch_bounds__(256) void k_add_image(float4* __restrict__ dst, const float4* __restrict__ src, int n_pixels) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 a = dst[i], b = src[i];
+    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+void launch_add_image(float4* dst, const float4* src, int n_pixels, hipStream_t st) {
+    hipLaunchKernelGGL(k_add_image, dim3((n_pixels + 255) / 256), dim3(256), 0, st, dst, src, n_pixels);
+}
 void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* out, hipStream_t st) {
     hipLaunchKernelGGL(k_sum_slices, dim3((n_pixels + 255) / 256), dim3(256), 0, st, part, n_pixels, n_slices, out);
 }

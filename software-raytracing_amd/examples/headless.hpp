@@ -26,6 +26,14 @@ inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
             return argv[++i];
         };
         if (std::strcmp(argv[i], "--bvh") == 0) o.bvh = true;
+        else if (const char* v = value("--gpus")) {          // 03/04: a device group over GPUs 0..N-1 (rt_create_multi)
+            std::vector<int32_t> ids; for (int k = 0, n = std::atoi(v); k < n; ++k) ids.push_back(k);
+            rtbackend::use_devices(ids);
+        } else if (const char* v = value("--devices")) {     // explicit list, e.g. 0,1 (an id may repeat: one-GPU rehearsal)
+            std::vector<int32_t> ids;
+            for (const char* p = v; *p;) { char* end = nullptr; long id = std::strtol(p, &end, 10); if (end == p) break; ids.push_back(static_cast<int32_t>(id)); p = (*end == ',') ? end + 1 : end; }
+            rtbackend::use_devices(ids);
+        }
         else if (const char* v = value("--width")) o.width = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--height")) o.height = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--samples")) o.samples = static_cast<unsigned>(std::atoi(v));
@@ -35,7 +43,7 @@ inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
         else if (const char* v = value("--checkpoint")) o.checkpoint = v;
         else if (const char* v = value("--chunk")) o.chunk = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--stop-after")) o.stopAfter = static_cast<unsigned>(std::atoi(v));
-        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after --bvh)");
+        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after --bvh --gpus --devices)");
     }
     return o;
 }
@@ -73,5 +81,5 @@ inline void PrintBackendStats() {
     rt_stats st{};
     if (rt_get_stats(rtbackend::context(), &st) == RT_OK)
         std::cout << "INFO: rays " << st.rays << ", shadow rays " << st.shadow_rays << ", samples " << st.samples
-                  << ", kernel " << st.kernel_ms << " ms, call " << st.total_ms << " ms" << std::endl;
+                  << ", kernel " << st.kernel_ms << " ms, call " << st.total_ms << " ms" << (st.allreduce_ms > 0 ? ", all-reduce " + std::to_string(st.allreduce_ms) + " ms" : std::string()) << std::endl;
 }

@@ -14,6 +14,7 @@ struct Tag : materials::Material {
     bool isScatters(const math::Ray&, const HitInfo&) const override { return false; }
     bool isEmits(const math::Ray&, const HitInfo&) const override { return false; }
     V3 emittedColor() const override { return {}; }
+    math::Ray scatteredRay(const math::Ray&, const HitInfo&, V3*) const override { return {}; }
     bool describe(rt_material*) const override { return false; }
 };
 }
@@ -38,5 +39,53 @@ extern "C" int hm_e4_scene_hit(const float* prims, int n, const float* o, const 
         out8[4] = h.normal.x; out8[5] = h.normal.y; out8[6] = h.normal.z; out8[7] = h.frontFaceSurface ? 1.0f : 0.0f;
         *which = static_cast<Tag*>(h.materialPtr.get())->idx;
     }
+    return hit;
+}
+
+// n scatters of one host material at one hit (the reference interface: isScatters / isEmits / scatteredRay / emittedColor).
+// kind 1 diffuse, 2 metal(rough), 3 refractive(index), 4 light.  out: dirs[3n], atts[3n], flags[2], emitted[3]
+extern "C" void hm_e4_scatter(int kind, const float* albedo, float param, const float* in_d, const float* point, const float* normal, int front,
+                              int n, float* out_dirs, float* out_atts, int* flags, float* emitted) {
+    std::shared_ptr<materials::Material> m;
+    if (kind == 1) m = std::make_shared<materials::Diffuse>(v(albedo));
+    else if (kind == 2) m = std::make_shared<materials::Metal>(v(albedo), param);
+    else if (kind == 3) m = std::make_shared<materials::Refractive>(param);
+    else m = std::make_shared<materials::Light>(v(albedo));
+    HitInfo h{}; h.point = v(point); h.normal = v(normal); h.frontFaceSurface = front != 0; h.t = 1.0f;
+    math::Ray in; in.setOrigin(v(point)); in.setDirection(v(in_d), false);
+    flags[0] = m->isScatters(in, h); flags[1] = m->isEmits(in, h);
+    const V3 e = m->emittedColor(); emitted[0] = e.x; emitted[1] = e.y; emitted[2] = e.z;
+    for (int i = 0; i < n; ++i) {
+        V3 att(0, 0, 0);
+        const math::Ray sr = m->scatteredRay(in, h, &att);
+        const V3 d = sr.getDirection();
+        out_dirs[3 * i] = d.x; out_dirs[3 * i + 1] = d.y; out_dirs[3 * i + 2] = d.z;
+        out_atts[3 * i] = att.x; out_atts[3 * i + 1] = att.y; out_atts[3 * i + 2] = att.z;
+    }
+}
+// A nested list and a triangle element, flattened as Render() does: returns the number of flat primitives and their types.
+extern "C" int hm_e4_flatten_nested(int* types, int cap) {
+    auto white = std::make_shared<materials::Diffuse>(V3(0.7f, 0.7f, 0.7f));
+    auto inner = std::make_shared<scene::List>();
+    inner->addElement(std::make_shared<scene::Sphere>(white, V3(0, 0, -3), 1.0f));
+    inner->addElement(std::make_shared<scene::Triangle>(white, V3(-1, 0, -2), V3(1, 0, -2), V3(0, 1, -2)));
+    auto deeper = std::make_shared<scene::List>(std::make_shared<scene::Plane>(white, V3(0, -1, 0), V3(0, 1, 0)));
+    inner->addElement(deeper);
+    scene::List world;
+    world.addElement(std::make_shared<scene::Plane>(white, V3(0, 5, 0), V3(0, -1, 0)));
+    world.addElement(inner);
+    world.addElement(std::make_shared<scene::Rectangle>(white, V3(0, 4, 0), math::Vec2<float>(1, 1), V3(90, 0, 0)));
+    rtbackend::Flat flat;
+    path_detail::flatten(world.getElements(), &flat);
+    for (size_t i = 0; i < flat.prims.size() && static_cast<int>(i) < cap; ++i) types[i] = flat.prims[i].type;
+    return static_cast<int>(flat.prims.size()) * 100 + static_cast<int>(flat.mats.size());
+}
+// host Triangle element against the raw routine (same t; normal turned against the ray)
+extern "C" int hm_e4_triangle_hit(const float* v0, const float* v1, const float* v2, const float* o, const float* d, float tmin, float tmax, float* out8) {
+    scene::Triangle tri(nullptr, v(v0), v(v1), v(v2));
+    math::Ray ray; ray.setOrigin(v(o)); ray.setDirection(v(d), false);
+    HitInfo h{};
+    const bool hit = tri.intersectsRay(ray, tmin, tmax, &h);
+    if (hit) { out8[0] = h.t; out8[1] = h.point.x; out8[2] = h.point.y; out8[3] = h.point.z; out8[4] = h.normal.x; out8[5] = h.normal.y; out8[6] = h.normal.z; out8[7] = h.frontFaceSurface ? 1.0f : 0.0f; }
     return hit;
 }

@@ -10,6 +10,10 @@ namespace path_detail {
 template <class ElementList> inline void flatten(const ElementList& elements, rtbackend::Flat* flat) {
     for (const auto& e : elements) {
         rt_prim p{};
+        if (const auto* nested = dynamic_cast<const Scene*>(e.get())) {      // a Scene inside a Scene (Utils.h:199): its elements, in place and in order
+            flatten(nested->getElements(), flat);
+            continue;
+        }
         if (!e || !e->describe(&p)) throw std::runtime_error("ERROR: scene element without a GPU description (describe() returned false)");
         p.material = -1;                                         // element without material: absorbs (black)
         if (const auto& m = e->getMaterial()) {

@@ -9,6 +9,7 @@
 #include "Scene/Plane.hpp"
 #include "Scene/Rectangle.hpp"
 #include "Scene/Sphere.hpp"
+#include "Scene/Triangle.hpp"
 
 inline uint32_t& RenderSeed() { static uint32_t seed = 1u; return seed; }
 
@@ -16,6 +17,10 @@ namespace path_detail {
 template <class ElementList> inline void flatten(const ElementList& elements, rtbackend::Flat* flat) {
     for (const auto& e : elements) {
         rt_prim p{};
+        if (const auto* nested = dynamic_cast<const scene::List*>(e.get())) {      // a List inside a List (Utils.h:306): its elements, in place and in order
+            flatten(nested->getElements(), flat);
+            continue;
+        }
         if (!e || !e->describe(&p)) throw std::runtime_error("ERROR: scene element without a GPU description (describe() returned false)");
         p.material = -1;                                         // no material: the path ends black (Main.cpp:485-498)
         if (const auto& m = e->getMaterial()) {

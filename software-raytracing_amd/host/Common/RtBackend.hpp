@@ -2,6 +2,7 @@
 // (the reference's main() catches std::exception, 01_Basic/Main.cpp:230-233), and RGBQUAD for non-Windows hosts.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -15,8 +16,25 @@ using BYTE = uint8_t;
 static_assert(sizeof(RGBQUAD) == 4, "RGBQUAD must be 4 bytes: the kernels write B,G,R,255 straight into it");
 
 namespace rtbackend {
+// The GPUs the process-wide context spans: empty = the current device; several entries = a device group (rt_create_multi:
+// sample ranges over the devices, one RCCL all-reduce, the first device resolves).  Set before the first Render() - by
+// use_devices(), or by the environment: RT_MI355_DEVICES="0,1,2,3" or RT_MI355_GPUS=4 (devices 0..3).
+inline std::vector<int32_t>& devices() {
+    static std::vector<int32_t> d = [] {
+        std::vector<int32_t> v;
+        if (const char* e = std::getenv("RT_MI355_DEVICES")) {
+            for (const char* p = e; *p;) { char* end = nullptr; long id = std::strtol(p, &end, 10); if (end == p) break; v.push_back(static_cast<int32_t>(id)); p = (*end == ',') ? end + 1 : end; }
+        } else if (const char* e = std::getenv("RT_MI355_GPUS")) {
+            for (int i = 0, n = std::atoi(e); i < n; ++i) v.push_back(i);
+        }
+        return v;
+    }();
+    return d;
+}
+inline void use_devices(const std::vector<int32_t>& ids) { devices() = ids; }
 inline rt_ctx* context() {
-    static rt_ctx* ctx = rt_create(-1);
+    static rt_ctx* ctx = devices().size() > 1 ? rt_create_multi(devices().data(), static_cast<int32_t>(devices().size()))
+                                              : rt_create(devices().empty() ? -1 : devices()[0]);
     if (!ctx) throw std::runtime_error(std::string("ERROR: no MI355X tracing backend: ") + rt_last_error(nullptr));
     return ctx;
 }

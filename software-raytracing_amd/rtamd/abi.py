@@ -60,14 +60,14 @@ class rt_path_params(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("samples", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("allreduce_ms", C.c_double)]
 
 
 assert C.sizeof(rt_prim) == 64 and C.sizeof(rt_material) == 48 and C.sizeof(rt_light) == 32
 
 # every symbol include/rt_mi355.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_get_stats", "rt_abi_version",
+    "rt_create", "rt_create_multi", "rt_destroy", "rt_last_error", "rt_get_stats", "rt_abi_version",
     "rt_whitted_params_default", "rt_path_params_default",
     "rt_render_whitted", "rt_render_path",
     "rt_path_accumulate_device", "rt_path_accumulate_device_noalloc", "rt_noalloc_limits", "rt_whitted_device", "rt_resolve_device", "rt_sync", "rt_set_option",

@@ -28,6 +28,8 @@ def load():
         P = C.POINTER
         L.rt_create.restype = C.c_void_p
         L.rt_create.argtypes = [C.c_int32]
+        L.rt_create_multi.restype = C.c_void_p
+        L.rt_create_multi.argtypes = [P(C.c_int32), C.c_int32]
         L.rt_destroy.argtypes = [C.c_void_p]
         L.rt_last_error.restype = C.c_char_p
         L.rt_last_error.argtypes = [C.c_void_p]
@@ -57,9 +59,14 @@ def load():
 class Context:
     """rt_ctx owner.  One per process/device (the four Render wrappers share one)."""
 
-    def __init__(self, device_id=-1):
+    def __init__(self, device_id=-1, devices=None):
+        """devices: a list of HIP device ids -> a device group (rt_create_multi); else one device"""
         self.L = load()
-        self.h = self.L.rt_create(device_id)
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*devices)
+            self.h = self.L.rt_create_multi(arr, len(devices))
+        else:
+            self.h = self.L.rt_create(device_id)
         if not self.h:
             raise RtError(abi.RT_ERR_NO_DEVICE, self.L.rt_last_error(None).decode())
 
@@ -81,7 +88,7 @@ class Context:
     def stats(self):
         st = abi.rt_stats()
         self._chk(self.L.rt_get_stats(self.h, C.byref(st)))
-        return dict(rays=st.rays, shadow_rays=st.shadow_rays, samples=st.samples, kernel_ms=st.kernel_ms, total_ms=st.total_ms)
+        return dict(rays=st.rays, shadow_rays=st.shadow_rays, samples=st.samples, kernel_ms=st.kernel_ms, total_ms=st.total_ms, allreduce_ms=st.allreduce_ms)
 
     # ---- host-buffer entry points ---------------------------------------------------------
     def _image(self, width, height, want_rgb=True):

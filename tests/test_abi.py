@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     L = lib.load()
     for name in _declared():
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 1
+    assert L.rt_abi_version() == 2
 
 
 def test_record_sizes_match_header():
@@ -119,3 +119,18 @@ def test_bvh_builder_covers_every_bounded_slot_exactly_once():
     for k in range(300):
         s.sphere(w, (1, 2, 3), 0.5)
     r = probe(s); assert r["refs"] == 300 and r["depth"] <= 10
+
+
+def test_device_group_partition_covers_every_sample_once():
+    """rt_create_multi cuts [sample_begin, sample_end) into one contiguous share per device: no gap, no overlap, sizes within one."""
+    L = lib.load()
+    b, e = C.c_int32(), C.c_int32()
+    for (s0, s1) in ((0, 1024), (0, 1), (3, 10), (5, 5), (0, 1000)):
+        for n in (1, 2, 3, 4, 8):
+            cur, sizes = s0, []
+            for i in range(n):
+                assert L.rt_debug_group_share(s0, s1, i, n, C.byref(b), C.byref(e)) == 0
+                assert b.value == cur and e.value >= b.value
+                cur = e.value; sizes.append(e.value - b.value)
+            assert cur == s1 and max(sizes) - min(sizes) <= 1
+    assert L.rt_debug_group_share(0, 4, 2, 2, C.byref(b), C.byref(e)) == abi.RT_ERR_BAD_ARG

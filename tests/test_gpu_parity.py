@@ -490,6 +490,30 @@ def test_sample_range_sharding_is_additive(ctx):
     assert float(parts[0].abs().max()) == 0.0
 
 
+def test_device_group_equals_single_device(ctx):
+    """rt_create_multi, rehearsed on this one GPU (the same device listed three times: sample ranges, three accumulators, the
+    sum through the root-gather form, resolve on the first): the same paths as one context - ray and sample counts add up
+    exactly - and the same frame up to the order of the float additions.  Also with fewer samples than devices."""
+    s, cam, prm = scenes.scene04(25, seed=6)
+    one = ctx.render_path(s, cam, prm, 200, 136)
+    grp = lib.Context(devices=[0, 0, 0])
+    try:
+        g = grp.render_path(s, cam, prm, 200, 136)
+        assert g["rays"] == one["rays"] and g["samples"] == one["samples"] == 200 * 136 * 25
+        assert g["allreduce_ms"] > 0.0 and one["allreduce_ms"] == 0.0
+        assert np.allclose(g["rgb"], one["rgb"], rtol=1e-5, atol=1e-7)
+        assert (np.abs(g["bgra"].astype(int) - one["bgra"].astype(int)) <= 1).all()
+        s2, cam2, prm2 = scenes.scene03(2, seed=6)                       # 2 samples over 3 devices: one share is empty
+        a = ctx.render_path(s2, cam2, prm2, 120, 80)
+        b = grp.render_path(s2, cam2, prm2, 120, 80)
+        assert a["rays"] == b["rays"] and b["samples"] == 120 * 80 * 2
+        assert np.allclose(a["rgb"], b["rgb"], rtol=1e-5, atol=1e-7)
+        s1, cam1, prm1 = scenes.scene01()                                # Whitted frames stay on the first device
+        assert np.array_equal(grp.render_whitted(s1, cam1, prm1, 196, 140)["bgra"], ctx.render_whitted(s1, cam1, prm1, 196, 140)["bgra"])
+    finally:
+        grp.close()
+
+
 def test_resolve_is_bit_exact(ctx):
     import torch
     rng = np.random.default_rng(0)

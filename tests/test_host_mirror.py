@@ -98,6 +98,75 @@ def test_host_04_scene_classes_match_reference_vectors(fixture, tmin):
                 assert which.value == k["which"][s, r] and same(out, k["out"][s, r]), (s, r, out, k["out"][s, r])
 
 
+def test_host_materials_keep_the_reference_scatter_interface():
+    """materials::Material::scatteredRay (04) and Material::scatter (03) on the host - kept so that code written against the
+    reference's headers compiles and runs - follow the reference's rules: direction statistics and attenuations against the
+    statistics recorded from the reference's own classes (stat_samplers_materials.npz), Light's flags and colour."""
+    k = np.load(os.path.join(GOLDEN, "stat_samplers_materials.npz"))
+    L4 = C.CDLL(_need(os.path.join(BIN, "libhostmirror_e4.so")))
+    L3 = C.CDLL(_need(os.path.join(BIN, "libhostmirror_e3.so")))
+    IP = C.POINTER(C.c_int)
+    L4.hm_e4_scatter.argtypes = [C.c_int, FP, C.c_float, FP, FP, FP, C.c_int, C.c_int, FP, FP, IP, FP]
+    L3.hm_e3_scatter.argtypes = [C.c_int, FP, C.c_float, FP, FP, FP, C.c_int, C.c_int, FP, FP]
+    nrm = np.array([0, 1, 0], np.float32); pt = np.array([0.5, 0, -1], np.float32); ind = np.array([0.6, -0.8, 0.0], np.float32)
+    alb = np.array([0.8, 0.6, 0.2], np.float32)
+    n = 40000
+    dirs = np.zeros((n, 3), np.float32); atts = np.zeros((n, 3), np.float32); flags = (C.c_int * 2)(); em = np.zeros(3, np.float32)
+    for kind, name, param in ((1, "diffuse", 0.0), (2, "metal", 0.2)):
+        L4.hm_e4_scatter(kind, fp(alb), param, fp(ind), fp(pt), fp(nrm), 1, n, fp(dirs), fp(atts), flags, fp(em))
+        assert list(flags) == list(k[f"e4_{name}_flags"]) == [1, 0]
+        assert np.allclose(dirs.mean(axis=0), k[f"e4_{name}_dir_mean"], atol=8e-3), name
+        assert np.allclose(atts.mean(axis=0), k[f"e4_{name}_att_mean"], rtol=0.02), name
+        assert np.abs(atts - alb[None] * np.maximum(dirs @ nrm, 0)[:, None]).max() < 1e-6      # albedo * cos, no 2x pdf factor
+        att3 = np.zeros(3, np.float32)
+        assert L3.hm_e3_scatter(kind, fp(alb), param, fp(ind), fp(pt), fp(nrm), 1, n, fp(dirs), fp(att3)) == 1
+        assert np.allclose(dirs.mean(axis=0), k[f"e3_{name}_dir_mean"], atol=8e-3), name
+        assert np.allclose(att3, k[f"e3_{name}_att"]) and np.allclose(att3, alb)                 # 03: attenuation = albedo
+    att3 = np.zeros(3, np.float32)                                                               # 03 metal, roughness 0: the exact mirror direction
+    L3.hm_e3_scatter(2, fp(alb), 0.0, fp(ind), fp(pt), fp(nrm), 1, 1, fp(dirs), fp(att3))
+    assert same(dirs[0], k["e3_metal_mirror_dir"][0])
+    # dielectric (both examples): the refracted share at five angles of incidence, front and back face
+    for li, call in enumerate((lambda *a: L3.hm_e3_scatter(3, fp(alb), 0.6, *a, fp(dirs), fp(att3)),
+                               lambda *a: L4.hm_e4_scatter(3, fp(alb), 0.6, *a, fp(dirs), fp(atts), flags, fp(em)))):
+        for ci, cc in enumerate(k["dielectric_cosines"]):
+            vin = np.array([np.sqrt(1 - cc * cc), -cc, 0], np.float32)
+            for back in (0, 1):
+                call(fp(vin), fp(pt), fp(nrm), 0 if back else 1, 6000)
+                refl = k["dielectric_dirs"][li, back, ci, 0]
+                frac_refracted = 1.0 - (np.abs(dirs[:6000] - refl[None]).max(axis=1) < 1e-6).mean()
+                if np.abs(k["dielectric_dirs"][li, back, ci, 1] - refl).max() < 1e-6:
+                    continue                                                                   # total internal reflection: both outcomes coincide
+                assert abs(frac_refracted - k["dielectric_refract_fraction"][li, back, ci]) < 0.03, (li, ci, back)
+    L4.hm_e4_scatter(4, fp(alb), 0.0, fp(ind), fp(pt), fp(nrm), 1, 1, fp(dirs), fp(atts), flags, fp(em))
+    assert list(flags) == list(k["e4_light_front"]) == [0, 1] and np.allclose(em, k["e4_light_emitted"] * 0 + alb)
+    L4.hm_e4_scatter(4, fp(alb), 0.0, fp(ind), fp(pt), fp(nrm), 0, 1, fp(dirs), fp(atts), flags, fp(em))
+    assert list(flags) == list(k["e4_light_back"]) == [0, 0]
+
+
+def test_nested_lists_and_triangle_element_flatten_and_hit(H):
+    """scene::List inside scene::List (and Scene inside Scene) flatten to their elements in order; the host Triangle element
+    reports the raw routine's t (bit for bit, reference vectors) with the normal turned against the ray."""
+    L4 = C.CDLL(_need(os.path.join(BIN, "libhostmirror_e4.so")))
+    L3 = C.CDLL(_need(os.path.join(BIN, "libhostmirror_e3.so")))
+    types = (C.c_int * 16)()
+    assert L4.hm_e4_flatten_nested(types, 16) == 5 * 100 + 1          # plane, [sphere, triangle, [plane]], rectangle; one shared material
+    assert list(types[:5]) == [abi.RT_PRIM_PLANE, abi.RT_PRIM_SPHERE, abi.RT_PRIM_TRIANGLE, abi.RT_PRIM_PLANE, abi.RT_PRIM_RECT]
+    assert L3.hm_e3_flatten_nested() == 3
+    k = np.load(os.path.join(GOLDEN, "kat_intersect.npz"))
+    L4.hm_e4_triangle_hit.argtypes = [FP] * 5 + [C.c_float, C.c_float, FP]
+    out = np.zeros(8, np.float32)
+    hits = 0
+    for i in range(0, 1500):
+        v0, v1, v2 = (np.ascontiguousarray(k[n][i]) for n in ("v0", "v1", "v2"))
+        o, d = np.ascontiguousarray(k["o"][i]), np.ascontiguousarray(k["dtri"][i])
+        h = L4.hm_e4_triangle_hit(fp(v0), fp(v1), fp(v2), fp(o), fp(d), float(k["tmin"][i]), 1000.0, fp(out))
+        assert h == k["tr_hit"][i], i
+        if h:
+            hits += 1
+            assert same(out[0], k["tr_t"][i]) and np.dot(out[4:7], d) <= 0 and abs(np.linalg.norm(out[4:7]) - 1) < 1e-5
+    assert hits > 50
+
+
 def _load_dump(path):
     raw = open(path, "rb").read()
     n = np.frombuffer(raw, np.int32, 3)
@@ -189,6 +258,20 @@ def test_progressive_checkpointed_render_equals_one_shot(tmp_path):
     # a checkpoint of another frame is refused
     bad = subprocess.run(base[:-2] + ["--seed", "4", "--chunk", "10", "--checkpoint", ck], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 1 and "is not a checkpoint of this frame" in bad.stdout
+
+
+@pytest.mark.gpu
+def test_example04_device_group_flag(tmp_path):
+    """example04 --devices 0,0 (C++ Render -> rtbackend::context() -> rt_create_multi -> sample ranges, sum, resolve): the
+    one-context frame up to the order of the float additions (+-1 LSB on a few bytes)."""
+    exe = _need(os.path.join(BIN, "example04"))
+    base = [exe, "--width", "160", "--height", "120", "--samples", "16", "--seed", "5"]
+    a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    subprocess.run(base + ["--out", a], check=True, capture_output=True, timeout=120)
+    p = subprocess.run(base + ["--devices", "0,0", "--out", b], check=True, capture_output=True, text=True, timeout=120)
+    assert "all-reduce" in p.stdout
+    x, y = _read_ppm(a).astype(int), _read_ppm(b).astype(int)
+    assert np.abs(x - y).max() <= 1 and (x != y).mean() < 0.01
 
 
 @pytest.mark.gpu
