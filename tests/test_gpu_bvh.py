@@ -8,6 +8,7 @@ arbitrary orientations, triangles, planes (unbounded: outside the tree), empty s
 import numpy as np
 import pytest
 
+from conftest import nest_scene
 from rtamd import abi, scenes
 import orc as oracle
 
@@ -53,21 +54,7 @@ def test_bvh_ties_and_rays_starting_inside_overlapping_spheres(ctx):
     """Coincident duplicates (exact ties: the LAST one in scene order must win - they differ in material), glass spheres
     nested and intersecting so that rays inside one sphere find another surface before its far wall (the tMax rule hands
     the hit to the enclosing sphere when it comes later in scene order), rotated boxes, a rectangle coplanar with a box face."""
-    s = scenes.Scene()
-    white = s.diffuse((0.8, 0.8, 0.8)); red = s.diffuse((0.8, 0.1, 0.1)); green = s.diffuse((0.1, 0.8, 0.1))
-    glass = s.dielectric(0.66); glass2 = s.dielectric(0.8); metal = s.metal((0.9, 0.9, 0.9), 0.05); lm = s.light_material((9, 9, 9))
-    s.plane(white, (0, -2, 0), (0, 1, 0))
-    s.sphere(glass, (0, 0, -6), 1.0); s.sphere(red, (0, 0, -6), 0.5)              # a solid inside glass: found before the far wall
-    s.sphere(glass2, (0.3, 0, -6), 1.6)                                          # encloses both, LATER in scene order
-    s.sphere(glass, (2.2, 0, -6), 1.2); s.sphere(glass2, (3.2, 0.2, -6), 1.2)    # intersecting glass
-    s.sphere(red, (-3, 0, -7), 1.0); s.sphere(green, (-3, 0, -7), 1.0)           # coincident: green wins
-    s.rect(red, (0, 3, -7), (2, 2), (90, 0, 0)); s.rect(green, (0, 3, -7), (2, 2), (90, 0, 0))
-    s.triangle(red, (-6, -2, -9), (-2, -2, -11), (-4, 3, -10)); s.triangle(metal, (-6, -2, -9), (-2, -2, -11), (-4, 3, -10))
-    s.box(metal, (3, -1, -9), (2, 2, 2), (10, 30, 5)); s.box(glass, (-1.5, -1.2, -4), (1.2, 1.6, 1.2), (0, 20, 0))
-    s.rect(green, (3, -1, -8), (2, 2), (0, 0, 0))
-    s.sphere(white, (0.3, 0, -6), 2.4, flip=True)                                # an inverted shell around the nest, last: takes what starts inside it
-    s.rect(lm, (0, 6, -6), (6, 6), (90, 0, 0))
-    cam = scenes.camera(70.0, (0, 0.5, 1.0), (-3, 0, 0))
+    s, cam = nest_scene()
     for variant, depth in ((abi.RT_PATH_LIGHTS, 8), (abi.RT_PATH_SKY, 16)):
         prm = scenes.path_params(variant, 16, max_depth=depth, seed=9)
         a, b = _both(ctx, s, cam, prm, 160, 120)

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import frac_within, load_png_rgb
+from conftest import frac_within, load_png_rgb, nest_scene
 from rtamd import abi, lib, scenes
 import orc as oracle
 
@@ -355,6 +355,68 @@ def test_key_form_of_the_generated_query_is_bit_identical(ctx, which, monkeypatc
         finally:
             ctx.set_debug_flags(0)
     assert img["1"]["rays"] == img["2"]["rays"] and np.array_equal(img["1"]["rgb"], img["2"]["rgb"])
+
+
+@pytest.mark.parametrize("variant,depth,spp", [(abi.RT_PATH_LIGHTS, 8, 4), (abi.RT_PATH_SKY, 16, 2)])     # 03: chains of up to 17 glass bounces, so fewer paths per pixel
+def test_ties_and_tmax_rule_same_paths_as_oracle(ctx, variant, depth, spp):
+    """The scene of exact ties (last element wins) and nested / intersecting glass spheres (hit AT tMax, Common/Ray.hpp:127-134)
+    through the brute-force kernels - generic and scene-specialised - against the ORACLE per pixel: colours and scene-query
+    counts.  (tests/test_gpu_bvh.py shows the BVH walk equal to these kernels bit for bit.)"""
+    import torch
+    s, cam = nest_scene()
+    prm = scenes.path_params(variant, spp, max_depth=depth, seed=9)
+    w, h = 160, 120
+    o = oracle.render_path_px(s, cam, prm, w, h, threads=8)
+    om = o["sum"] / spp
+    for flags, kind in ((8 | 4, 1), (16 | 4, 2)):
+        acc = torch.zeros(h, w, 4, device="cuda")
+        ctx.set_debug_flags(flags)
+        try:
+            ctx.path_accumulate_device(s, cam, prm, w, h, acc.data_ptr())
+            st = ctx.sync()
+            assert ctx.last_path_kernel()[0] == kind, ctx.last_path_kernel()
+        finally:
+            ctx.set_debug_flags(0)
+        a = acc.cpu().numpy()
+        px = a[:, :, 3].astype(np.int64)
+        assert px.sum() == st["rays"] and abs(int(st["rays"]) - int(o["rays"])) <= 5e-3 * o["rays"]
+        assert (px == o["px_rays"]).mean() >= 0.97, (kind, (px == o["px_rays"]).mean())
+        assert frac_within(a[:, :, :3] / spp, om, 1e-3) >= 0.97, (kind, frac_within(a[:, :, :3] / spp, om, 1e-3))
+
+
+def test_sphere_hit_at_tmax_decides_the_visible_material(ctx):
+    """Two spheres, hand-made.  A: an emissive shell of radius 100 around the camera with inverted normals; the query's tMax is
+    50, so a ray inside A has its near root behind and its far root beyond tMax, and the reference reports a hit AT tMax
+    (Common/Ray.hpp:127-134): the background glows although A's surface is out of range.  B: a small diffuse sphere in view.
+    Order (A, B): B is tested later against closest = tMax and wins its pixels.  Order (B, A): A comes after B, its far
+    root is not <= B's distance, and the rule hands A the hit at B's distance: B vanishes, every pixel shows A's emission."""
+    cam = scenes.camera(60.0, (0, 0, 0), (0, 0, 0))
+    prm = scenes.path_params(abi.RT_PATH_LIGHTS, 4, max_depth=3, seed=2, t_max=50.0)
+    w, h = 96, 64
+    imgs = {}
+    for order in ("AB", "BA"):
+        s = scenes.Scene()
+        glow = s.light_material((2.0, 1.5, 1.0)); grey = s.diffuse((0.5, 0.5, 0.5))
+        for c in order:
+            if c == "A":
+                s.sphere(glow, (0, 0, 0), 100.0, flip=True)
+            else:
+                s.sphere(grey, (0, 0, -5), 1.5)
+        o = oracle.render_path(s, cam, prm, w, h, threads=4)
+        om = o["sum"] / 4
+        for flags in (8, 16):                                   # generic loops, generated code
+            ctx.set_debug_flags(flags)
+            try:
+                g = ctx.render_path(s, cam, prm, w, h)
+            finally:
+                ctx.set_debug_flags(0)
+            assert g["rays"] == o["rays"], (order, flags)
+            assert frac_within(g["rgb"], om, 1e-4) >= 0.995, (order, flags)
+        imgs[order] = g["rgb"]
+    glow_rgb = np.array([2.0, 1.5, 1.0], np.float32)
+    assert np.allclose(imgs["BA"], glow_rgb[None, None], rtol=1e-6)                 # B vanished behind the rule
+    centre = imgs["AB"][h // 2 - 4:h // 2 + 4, w // 2 - 4:w // 2 + 4]
+    assert np.allclose(imgs["AB"][0, 0], glow_rgb, rtol=1e-6) and (centre < 0.9 * glow_rgb).all() and (centre > 0).all()   # B visible, lit by the glow
 
 
 def test_specialisation_policy_and_cache_across_scenes(ctx):
