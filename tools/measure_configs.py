@@ -1,4 +1,4 @@
-"""SURVEY.md 8(d) configs 1-5 on one GPU -> one JSON line each (profiles/r01_configs.jsonl).  Config 4 is what bench.py
+"""SURVEY.md 8(d) configs 1-5 on one GPU -> one JSON line each (profiles/rNN_configs.jsonl; "--no5" leaves config 5 out: its full-size run is tools/run_config5.py).  Config 4 is what bench.py
 reports; it is repeated here at the same size for one table.  Config 5 runs at a reduced frame/spp (the full 4K/4096-spp
 frame is ~1.6e15 primitive tests) with the full 18,194-primitive scene; its rate is per ray, so it carries over."""
 import json, os, sys
@@ -28,6 +28,7 @@ emit(3, "03_PathTracingBasics 1920x1080 256 spp depth 24", g, g["rays"] * scenes
 s, cam, prm = scenes.scene04(1024, seed=1)
 g = best(lambda: ctx.render_path(s, cam, prm, 3840, 2160), 3)
 emit(4, "04_PathTracingLights 3840x2160 1024 spp depth 6", g, g["rays"] * scenes.flops_per_ray(s, 100), {"rays_per_sample": g["rays"] / g["samples"]})
+if "--no5" in sys.argv: sys.exit(0)
 s, cam, prm = scenes.scene_stress(spp=16, seed=1)
 g = best(lambda: ctx.render_path(s, cam, prm, 1920, 1080), 1)
 emit(5, f"stress scene ({len(s.prims)} primitives, brute force) 1920x1080 16 spp depth 8 (reduced from 3840x2160, 4096 spp)", g, g["rays"] * scenes.flops_per_ray(s, 100),
