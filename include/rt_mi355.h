@@ -213,6 +213,22 @@ int32_t rt_render_whitted(rt_ctx* ctx, const rt_scene* scene, const rt_camera* c
 int32_t rt_render_path(rt_ctx* ctx, const rt_scene* scene, const rt_camera* camera,
                        const rt_path_params* params, const rt_image* out);
 
+/* ---- progressive frame (interactive preview) ----------------------------------------- */
+/* The reference's main() renders the whole frame, then shows it once (Render -> PresentFrame, 01 Main.cpp:206-215 and
+ * :272-310; the same in 02-04).  For an interactive viewer the path-traced frame is built up in passes instead: the running
+ * per-pixel sums stay in device memory between passes (16 B/pixel in HBM; nothing but the 4 B/pixel preview crosses PCIe),
+ * each pass adds the next n_samples samples of every pixel - the same samples the one-shot render takes, so the finished
+ * frame equals rt_render_path's up to the order of the float additions - and optionally resolves a preview exposed for the
+ * samples done so far (sum / done; sqrt; clamp; truncate).  Works on device groups (rt_create_multi) as rt_render_path does.
+ * One progressive frame per context; rt_progressive_begin copies the scene records.  params->sample_begin/end select the
+ * range the frame covers ((0,0) = [0, spp)).  rt_progressive_pass with n_samples = 0 only resolves; once the range is
+ * used up further passes render nothing.  samples_done (optional) receives the samples per pixel accumulated so far;
+ * rt_stats describes the pass.  Blocking. */
+int32_t rt_progressive_begin(rt_ctx* ctx, const rt_scene* scene, const rt_camera* camera,
+                             const rt_path_params* params, int32_t width, int32_t height);
+int32_t rt_progressive_pass(rt_ctx* ctx, int32_t n_samples, const rt_image* preview, int32_t* samples_done);
+int32_t rt_progressive_end(rt_ctx* ctx);
+
 /* ---- device-buffer entry points (bench / multi-GPU composition) ----------------------- */
 /* Same kernels, but outputs stay in device memory the caller owns (e.g. a torch tensor), so
  * per-GPU sample-range partial sums can be all-reduced (RCCL) before resolve.  'stream' is a

@@ -146,6 +146,14 @@ struct rt_ctx {
     hipEvent_t ar0 = nullptr, ar1 = nullptr;      // timing of the sum on this device's stream
     void* rccl_lib = nullptr; std::vector<void*> comms;   // RCCL communicators, one per device of the group (all devices distinct)
     DevBuf gather;                                // root-gather form: a peer's accumulator copied to this device
+    // progressive frame (rt_progressive_*): the running sums stay in device memory between passes; the session keeps its own
+    // copy of the scene records so that the caller's may go away between passes
+    struct Progressive {
+        bool active = false; int W = 0, H = 0, begin = 0, end = 0, done = 0;
+        rt_path_params params{}; rt_camera cam{};
+        std::vector<rt_prim> prims; std::vector<rt_material> mats; std::vector<rt_light> lights;
+    } prog;
+    DevBuf prog_sum;
     int accel = 0;                                // RT_OPT_ACCEL: 0 brute force (the reference's algorithm), 1 BVH
     // what scene_buf holds: a render of the same scene (same bytes, variant, BVH or not, stream) skips compile, build and upload
     bool cache_valid = false; uint64_t cache_key = 0; hipStream_t cache_stream = nullptr;
@@ -581,7 +589,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->ar1) (void)hipEventDestroy(c->ar1);
     c->gather.release();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->scene_buf.release(); c->partial.release(); c->accum.release(); c->bgra.release(); c->rgb.release();
+    c->scene_buf.release(); c->partial.release(); c->accum.release(); c->bgra.release(); c->rgb.release(); c->prog_sum.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -929,6 +937,81 @@ int32_t rt_render_path(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, c
     if (!c) return RT_ERR_BAD_ARG;
     if (!p) return fail(c, RT_ERR_BAD_ARG, "params is null");
     return render_host(c, scene, cam, nullptr, p, out);
+}
+
+// ---- progressive frame: sums resident in HBM, a preview per pass ---------------------------------------------------------
+
+int32_t rt_progressive_begin(rt_ctx* c, const rt_scene* scene, const rt_camera* cam, const rt_path_params* p, int32_t width, int32_t height) {
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!scene || !cam || !p) return fail(c, RT_ERR_BAD_ARG, "rt_progressive_begin: null argument");
+    if (width <= 0 || height <= 0 || (size_t)width * height > ((size_t)1 << 28)) return fail(c, RT_ERR_BAD_ARG, "rt_progressive_begin: bad image size");
+    if (scene->n_prims < 0 || scene->n_materials < 0 || scene->n_lights < 0 || (scene->n_prims && !scene->prims) || (scene->n_materials && !scene->materials) || (scene->n_lights && !scene->lights))
+        return fail(c, RT_ERR_BAD_ARG, "rt_progressive_begin: scene arrays");
+    int s0 = p->sample_begin, s1 = p->sample_end;
+    if (s0 == 0 && s1 == 0) s1 = p->spp;
+    if (p->spp <= 0 || s0 < 0 || s1 < s0 || s1 > p->spp) return fail(c, RT_ERR_BAD_ARG, "rt_progressive_begin: bad spp / sample range");
+    auto& g = c->prog;
+    g.active = false;
+    HIPCHK(c, c->prog_sum.reserve((size_t)width * height * sizeof(float4)));
+    HIPCHK(c, hipMemsetAsync(c->prog_sum.p, 0, (size_t)width * height * sizeof(float4), c->stream));
+    g.prims.assign(scene->prims, scene->prims + scene->n_prims);
+    g.mats.assign(scene->materials, scene->materials + scene->n_materials);
+    g.lights.assign(scene->lights, scene->lights + scene->n_lights);
+    g.params = *p; g.cam = *cam; g.W = width; g.H = height; g.begin = s0; g.end = s1; g.done = 0;
+    g.active = true;
+    return RT_OK;
+}
+
+int32_t rt_progressive_pass(rt_ctx* c, int32_t n_samples, const rt_image* preview, int32_t* samples_done) {
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = check_ctx(c); if (rc) return rc;
+    auto& g = c->prog;
+    if (!g.active) return fail(c, RT_ERR_BAD_ARG, "rt_progressive_pass: no progressive frame (rt_progressive_begin)");
+    if (n_samples < 0) return fail(c, RT_ERR_BAD_ARG, "rt_progressive_pass: negative sample count");
+    const int W = g.W, Hh = g.H;
+    const size_t npx = (size_t)W * Hh;
+    int stride = 0;
+    if (preview) {
+        if (preview->width != W || preview->height != Hh || (!preview->bgra && !preview->rgb)) return fail(c, RT_ERR_BAD_ARG, "rt_progressive_pass: preview image must have the frame's size and a buffer");
+        stride = preview->bgra_stride_bytes ? preview->bgra_stride_bytes : W * 4;
+        if (stride < W * 4 || (stride & 3)) return fail(c, RT_ERR_BAD_ARG, "bgra stride must be >= width*4 and a multiple of 4");
+    }
+    const int b = g.begin + g.done, e = (long long)b + n_samples < g.end ? b + n_samples : g.end;
+    const bool group = !c->peers.empty();
+    const bool rendered = e > b;
+    c->stats.allreduce_ms = 0.0;
+    if (rendered) {
+        const rt_scene sc{g.prims.data(), (int32_t)g.prims.size(), g.mats.data(), (int32_t)g.mats.size(), g.lights.data(), (int32_t)g.lights.size()};
+        rt_path_params q = g.params; q.sample_begin = b; q.sample_end = e;
+        HIPCHK(c, c->accum.reserve(npx * sizeof(float4)));
+        rc = group ? path_accumulate_group(c, &sc, &g.cam, &q, W, Hh) : rt_path_accumulate_device(c, &sc, &g.cam, &q, W, Hh, (float*)c->accum.p, nullptr);
+        if (rc) return rc;
+        launch_add_image((float4*)c->prog_sum.p, (const float4*)c->accum.p, (int)npx, c->stream);
+        HIPCHK(c, hipGetLastError());
+        g.done += e - b;
+    } else { c->stats.rays = c->stats.shadow_rays = c->stats.samples = 0; c->stats.kernel_ms = 0.0; }
+    if (preview) {                                          // exposed for the samples done so far: sum / done, sqrt, clamp, truncate
+        if (preview->bgra) HIPCHK(c, c->bgra.reserve((size_t)stride * Hh));
+        if (preview->rgb) HIPCHK(c, c->rgb.reserve(npx * 3 * sizeof(float)));
+        rc = rt_resolve_device(c, (const float*)c->prog_sum.p, W, Hh, g.done ? (float)g.done : 1.0f, 1, preview->bgra ? (uint8_t*)c->bgra.p : nullptr, stride,
+                               preview->rgb ? (float*)c->rgb.p : nullptr, nullptr);
+        if (rc) return rc;
+        if (preview->bgra) HIPCHK(c, hipMemcpyAsync(preview->bgra, c->bgra.p, (size_t)stride * Hh, hipMemcpyDeviceToHost, c->stream));
+        if (preview->rgb) HIPCHK(c, hipMemcpyAsync(preview->rgb, c->rgb.p, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (rendered) { if ((rc = rt_sync(c, nullptr))) return rc; if (group && (rc = group_sync(c))) return rc; }
+    else HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stats.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (samples_done) *samples_done = g.done;
+    return RT_OK;
+}
+
+int32_t rt_progressive_end(rt_ctx* c) {
+    int rc = check_ctx(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->prog = rt_ctx::Progressive{};
+    c->prog_sum.release();
+    return RT_OK;
 }
 
 // test/bench hook: regeneration threshold (idle lanes per wave); <0 restores the default. Not part of rt_mi355.h.

@@ -36,6 +36,7 @@ int main(int argc, char* argv[]) {
         Render(&frameBuffer, 90.0f, scene, lightSources);
         std::cout << "INFO: Scene rendered in " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - renderBeginTime).count() << " ms." << std::endl;
         PrintBackendStats();
+        PresentOnce(frameBuffer, opt);
         WriteFrame(frameBuffer, opt.out);
     } catch (std::exception& ex) {
         std::cout << ex.what() << std::endl;

@@ -28,7 +28,17 @@ int main(int argc, char* argv[]) {
         rtbackend::context();   // device / library initialisation is not part of the render time reported below
         if (opt.bvh) rtbackend::check(rt_set_option(rtbackend::context(), RT_OPT_ACCEL, RT_ACCEL_BVH));
         auto renderBeginTime = std::chrono::system_clock::now();
+        if (opt.chunk && !opt.present.empty()) {
+            // interactive: --chunk samples per pass, every pass presented to --present (the sums stay on the GPU)
+            rtbackend::Flat flat; path_detail::flatten(scene.getElements(), &flat);
+            auto sink = MakeSink(opt.present);
+            const unsigned done = InteractiveRender(&frameBuffer, flat.scene(), rt_camera{50.0f, {-2.0f, 1.5f, 1.0f}, {-30.0f, -42.0f, 0.0f}}, 3, opt.samples, opt.chunk, RenderSeed(),
+                                                    *sink, [&](unsigned d) { return !(opt.stopAfter && d >= opt.stopAfter); });
+            std::cout << "INFO: " << done << " of " << opt.samples << " samples per pixel done, " << sink->framesPresented() << " frames presented" << std::endl;
+        } else {
         Render(&frameBuffer, scene, 50.0f, opt.samples, {-2.0f, 1.5f, 1.0f}, {-30.0f, -42.0f, 0.0f});
+        PresentOnce(frameBuffer, opt);
+        }
         std::cout << "INFO: Scene rendered in " << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - renderBeginTime).count() << " ms." << std::endl;
         PrintBackendStats();
         WriteFrame(frameBuffer, opt.out);

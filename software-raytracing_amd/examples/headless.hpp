@@ -7,11 +7,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <string>
+#include "../host/Common/Present.hpp"
 
 struct Options {
     unsigned width = 784, height = 561, samples = 0, seed = 1;
     std::string out, dump, checkpoint;
+    std::string present;                 // frame sink in place of the window: file.bmp (rewritten per frame), a raw B,G,R,x stream file / FIFO, or - (stdout)
     unsigned chunk = 0, stopAfter = 0;   // progressive rendering: samples per pass, stop early (to be resumed)
     bool bvh = false;                    // 03/04: query the scene through the optional BVH (same image, fewer primitive tests)
 };
@@ -39,13 +42,26 @@ inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
         else if (const char* v = value("--samples")) o.samples = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--seed")) o.seed = static_cast<unsigned>(std::strtoul(v, nullptr, 10));
         else if (const char* v = value("--out")) o.out = v;
+        else if (const char* v = value("--present")) o.present = v;
         else if (const char* v = value("--dump-scene")) o.dump = v;
         else if (const char* v = value("--checkpoint")) o.checkpoint = v;
         else if (const char* v = value("--chunk")) o.chunk = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--stop-after")) o.stopAfter = static_cast<unsigned>(std::atoi(v));
-        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after --bvh --gpus --devices)");
+        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after --bvh --gpus --devices --present)");
     }
     return o;
+}
+
+// The sink --present names: *.bmp -> BmpFileSink, anything else -> RawStreamSink
+inline std::unique_ptr<FrameSink> MakeSink(const std::string& path) {
+    if (path.size() > 4 && path.compare(path.size() - 4, 4, ".bmp") == 0) return std::unique_ptr<FrameSink>(new BmpFileSink(path));
+    return std::unique_ptr<FrameSink>(new RawStreamSink(path));
+}
+// What the reference's main() does after Render (01 Main.cpp:214-215): show the finished frame once.
+template <class FrameBuffer> inline void PresentOnce(FrameBuffer& fb, const Options& o) {
+    if (o.present.empty()) return;
+    auto sink = MakeSink(o.present);
+    PresentFrame(fb.getData(), static_cast<int>(fb.getWidth()), static_cast<int>(fb.getHeight()), *sink);
 }
 
 // P6 PPM, top row first, R,G,B from the B,G,R,reserved quads

@@ -3,6 +3,7 @@
 // Test support only; not part of librt_mi355.so.
 #include "../host/Common/Math.hpp"
 #include "../host/Common/Ray.hpp"
+#include "../host/Common/Present.hpp"
 
 using V = math::Vec3<float>;
 static V v(const float* p) { return {p[0], p[1], p[2]}; }
@@ -28,5 +29,13 @@ int hm_ray_triangle(const float* o, const float* d, const float* v0, const float
     int h = ray(o, d).intersectsTriangle(v(v0), v(v1), v(v2), tmin, tmax, t, &b);
     if (h) { bary[0] = b.x; bary[1] = b.y; }
     return h;
+}
+// Present.hpp sinks: 'times' presents of one frame whose first byte is bumped per present; 0 on success, 1 on an exception
+int hm_present(const char* path, int bmp, unsigned char* pixels, int w, int h, int times) {
+    try {
+        if (bmp) { BmpFileSink sink(path); for (int i = 0; i < times; ++i) { pixels[0] = static_cast<unsigned char>(i); PresentFrame(pixels, w, h, sink); } return sink.framesPresented() == static_cast<unsigned>(times) ? 0 : 1; }
+        RawStreamSink sink(path); for (int i = 0; i < times; ++i) { pixels[0] = static_cast<unsigned char>(i); PresentFrame(pixels, w, h, sink); }
+        return 0;
+    } catch (std::exception&) { return 1; }
 }
 }

@@ -69,6 +69,6 @@ assert C.sizeof(rt_prim) == 64 and C.sizeof(rt_material) == 48 and C.sizeof(rt_l
 EXPORTS = [
     "rt_create", "rt_create_multi", "rt_destroy", "rt_last_error", "rt_get_stats", "rt_abi_version",
     "rt_whitted_params_default", "rt_path_params_default",
-    "rt_render_whitted", "rt_render_path",
+    "rt_render_whitted", "rt_render_path", "rt_progressive_begin", "rt_progressive_pass", "rt_progressive_end",
     "rt_path_accumulate_device", "rt_path_accumulate_device_noalloc", "rt_noalloc_limits", "rt_whitted_device", "rt_resolve_device", "rt_sync", "rt_set_option",
 ]

@@ -38,6 +38,9 @@ def load():
         L.rt_path_params_default.argtypes = [C.c_int32, P(abi.rt_path_params)]
         L.rt_render_whitted.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_whitted_params), P(abi.rt_image)]
         L.rt_render_path.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_path_params), P(abi.rt_image)]
+        L.rt_progressive_begin.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_path_params), C.c_int32, C.c_int32]
+        L.rt_progressive_pass.argtypes = [C.c_void_p, C.c_int32, P(abi.rt_image), P(C.c_int32)]
+        L.rt_progressive_end.argtypes = [C.c_void_p]
         L.rt_path_accumulate_device.argtypes = [C.c_void_p, P(abi.rt_scene), P(abi.rt_camera), P(abi.rt_path_params),
                                                 C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.rt_path_accumulate_device_noalloc.argtypes = L.rt_path_accumulate_device.argtypes
@@ -108,6 +111,26 @@ class Context:
         sc = scene.c()
         self._chk(self.L.rt_render_path(self.h, C.byref(sc), C.byref(cam), C.byref(prm), C.byref(img)))
         return dict(bgra=bgra, rgb=rgb, **self.stats())
+
+    # ---- progressive frame: sums stay on the device, one preview per pass --------------------
+    def progressive_begin(self, scene, cam, prm, width, height):
+        sc = scene.c()
+        self._chk(self.L.rt_progressive_begin(self.h, C.byref(sc), C.byref(cam), C.byref(prm), width, height))
+        self._prog_size = (width, height)
+
+    def progressive_pass(self, n_samples, preview=True, want_rgb=True):
+        """-> dict(done=..., bgra=..., rgb=..., **stats of the pass); preview=False adds samples without reading a frame back"""
+        done = C.c_int32(0)
+        if preview:
+            img, bgra, rgb = self._image(*self._prog_size, want_rgb=want_rgb)
+            self._chk(self.L.rt_progressive_pass(self.h, n_samples, C.byref(img), C.byref(done)))
+        else:
+            bgra = rgb = None
+            self._chk(self.L.rt_progressive_pass(self.h, n_samples, None, C.byref(done)))
+        return dict(done=done.value, bgra=bgra, rgb=rgb, **self.stats())
+
+    def progressive_end(self):
+        self._chk(self.L.rt_progressive_end(self.h))
 
     # ---- device-buffer entry points (raw device pointers, e.g. torch tensor .data_ptr()) -----
     def path_accumulate_device(self, scene, cam, prm, width, height, d_accum_ptr, stream=None):

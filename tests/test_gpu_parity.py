@@ -678,3 +678,38 @@ def test_full_size_02_4k_sweep_ray_counts(ctx):
         s, cam, prm = scenes.scene02(samples)
         g = ctx.render_whitted(s, cam, prm, w, h)
         assert g["rays"] == w * h and g["shadow_rays"] == samples * w * h
+
+
+def test_progressive_frame_on_device_equals_one_shot(ctx):
+    """rt_progressive_begin/pass/end: the sums stay in HBM, passes of 3+3+2 samples give rt_render_path's 8-spp frame up to the
+    order of the float additions, with the same rays in total; the preview after the first pass is the frame of samples [0,3)
+    exposed for 3 samples; n_samples = 0 only resolves; passes beyond the range render nothing.  Also on a device group."""
+    s, cam, prm = scenes.scene04(8, seed=11)
+    w, h = 160, 120
+    one = ctx.render_path(s, cam, prm, w, h)
+    part = abi.rt_path_params.from_buffer_copy(prm); part.sample_begin, part.sample_end = 0, 3
+    first = ctx.render_path(s, cam, part, w, h)
+    groups = [ctx, lib.Context(devices=[0, 0])]
+    try:
+        for c in groups:
+            c.progressive_begin(s, cam, prm, w, h)
+            rays = 0
+            p1 = c.progressive_pass(3); rays += p1["rays"]
+            assert p1["done"] == 3 and p1["samples"] == w * h * 3
+            assert np.allclose(p1["rgb"], first["rgb"] * (8.0 / 3.0), rtol=2e-6, atol=1e-7)
+            p2 = c.progressive_pass(3, preview=False); rays += p2["rays"]
+            assert p2["done"] == 6 and p2["bgra"] is None
+            p3 = c.progressive_pass(5); rays += p3["rays"]                     # clipped to the 2 samples that are left
+            assert p3["done"] == 8 and p3["samples"] == w * h * 2
+            assert rays == one["rays"]
+            assert np.allclose(p3["rgb"], one["rgb"], rtol=2e-6, atol=1e-7)
+            assert np.abs(p3["bgra"].astype(int) - one["bgra"].astype(int)).max() <= 1
+            p4 = c.progressive_pass(0)                                          # resolve only
+            assert p4["done"] == 8 and p4["rays"] == 0 and np.array_equal(p4["bgra"], p3["bgra"])
+            p5 = c.progressive_pass(4)                                          # nothing left to render
+            assert p5["done"] == 8 and p5["rays"] == 0 and np.array_equal(p5["rgb"], p3["rgb"])
+            c.progressive_end()
+            with pytest.raises(lib.RtError):
+                c.progressive_pass(1)
+    finally:
+        groups[1].close()

@@ -260,6 +260,66 @@ def test_progressive_checkpointed_render_equals_one_shot(tmp_path):
     assert bad.returncode == 1 and "is not a checkpoint of this frame" in bad.stdout
 
 
+def test_present_sinks_write_what_a_viewer_reads(H, tmp_path):
+    """host/Common/Present.hpp (the reference's PresentFrame, 01 Main.cpp:272-310, with a sink where the window was): the BMP
+    sink leaves one complete 32-bit top-down BMP whose pixel bytes are the frame buffer's B,G,R,x quads as they are (last frame
+    wins, no temporary left behind); the raw sink appends frames."""
+    import struct
+    w, h = 5, 3
+    px = np.arange(w * h * 4, dtype=np.uint8) * 3 + 7
+    buf = px.copy()
+    bmp, raw = str(tmp_path / "frame.bmp"), str(tmp_path / "frames.raw")
+    H.hm_present.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    assert H.hm_present(bmp.encode(), 1, buf.ctypes.data, w, h, 3) == 0
+    d = open(bmp, "rb").read()
+    assert d[:2] == b"BM" and struct.unpack_from("<I", d, 2)[0] == len(d) == 54 + w * h * 4 and struct.unpack_from("<I", d, 10)[0] == 54
+    hdr, bw, bh, planes, bpp, comp = struct.unpack_from("<IiiHHI", d, 14)
+    assert (hdr, bw, bh, planes, bpp, comp) == (40, w, -h, 1, 32, 0)             # negative height: top row first
+    want = px.copy(); want[0] = 2                                                  # the third present
+    assert d[54:] == want.tobytes() and not os.path.exists(bmp + ".tmp")
+    buf = px.copy()
+    assert H.hm_present(raw.encode(), 0, buf.ctypes.data, w, h, 2) == 0
+    d = open(raw, "rb").read()
+    f0, f1 = px.copy(), px.copy(); f0[0] = 0; f1[0] = 1
+    assert d == f0.tobytes() + f1.tobytes()
+    assert H.hm_present(str(tmp_path / "no_such_dir" / "x.bmp").encode(), 1, buf.ctypes.data, w, h, 1) == 1
+
+
+@pytest.mark.gpu
+def test_interactive_render_presents_every_pass(ctx, tmp_path):
+    """example04 --chunk 4 --present frame.bmp (InteractiveRender: rt_progressive_* keep the sums on the GPU, one preview per
+    pass): 3 passes presented, the BMP holds the finished frame = the PPM written from the same buffer = the one-shot frame up to
+    the order of the float additions; the raw sink holds all three previews, each exposed like the final frame."""
+    exe = _need(os.path.join(BIN, "example04"))
+    w, h, spp = 160, 120, 12
+    base = [exe, "--width", str(w), "--height", str(h), "--samples", str(spp), "--seed", "3"]
+    one, fin, bmp, raw = (str(tmp_path / n) for n in ("one.ppm", "fin.ppm", "frame.bmp", "frames.raw"))
+    subprocess.run(base + ["--out", one], check=True, capture_output=True, timeout=120)
+    p = subprocess.run(base + ["--chunk", "4", "--present", bmp, "--out", fin], check=True, capture_output=True, text=True, timeout=120)
+    assert "INFO: 12 of 12 samples per pixel done, 3 frames presented" in p.stdout
+    a, b = _read_ppm(one).astype(int), _read_ppm(fin).astype(int)
+    assert np.abs(a - b).max() <= 1 and (a != b).mean() < 0.01
+    d = np.frombuffer(open(bmp, "rb").read()[54:], np.uint8).reshape(h, w, 4)
+    assert np.array_equal(d[:, :, 2::-1], b) and (d[:, :, 3] == 255).all()
+    subprocess.run(base + ["--chunk", "4", "--present", raw], check=True, capture_output=True, timeout=120)
+    f = np.frombuffer(open(raw, "rb").read(), np.uint8).reshape(3, h, w, 4)
+    assert np.array_equal(f[2], d)
+    sc, cam, prm = scenes.scene04(spp=spp, seed=3)              # every preview is the ctypes path's, byte for byte
+    ctx.progressive_begin(sc, cam, prm, w, h)
+    for k in range(3):
+        assert np.array_equal(f[k], ctx.progressive_pass(4)["bgra"]), k
+    ctx.progressive_end()
+    # 03 takes the same flags
+    exe3 = _need(os.path.join(BIN, "example03"))
+    p = subprocess.run([exe3, "--width", "96", "--height", "64", "--samples", "6", "--chunk", "4", "--present", bmp], check=True, capture_output=True, text=True, timeout=120)
+    assert "INFO: 6 of 6 samples per pixel done, 2 frames presented" in p.stdout
+    # and 01 presents its finished frame once, as the reference's main() does
+    exe1 = _need(os.path.join(BIN, "example01"))
+    subprocess.run([exe1, "--width", "96", "--height", "64", "--present", bmp, "--out", fin], check=True, capture_output=True, timeout=120)
+    d = np.frombuffer(open(bmp, "rb").read()[54:], np.uint8).reshape(64, 96, 4)
+    assert np.array_equal(d[:, :, 2::-1], _read_ppm(fin))
+
+
 @pytest.mark.gpu
 def test_example04_device_group_flag(tmp_path):
     """example04 --devices 0,0 (C++ Render -> rtbackend::context() -> rt_create_multi -> sample ranges, sum, resolve): the
