@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=16)
+    ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a run that is still going prints every thread's stack and exits (0 = off): a rank stuck in a collective must not hang the job")
     args = ap.parse_args()
 
     import torch
@@ -97,6 +98,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to time")
     # BENCH_REHEARSAL=1: rehearse the N > 1 code path on a box with ONE GPU - every rank on device 0, gloo instead of RCCL
@@ -136,6 +140,13 @@ def main():
             else:
                 ctx.path_accumulate_device(s, cam, prm, W, H, accum.data_ptr(), sp)
             if world > 1:
+                # The host waits for this rank's render before the collective is issued (it reads the ray counter here anyway;
+                # the cost is one launch latency per frame).  Found by the rehearsal: with two processes on ONE GPU, gloo's CUDA
+                # all-reduce (event wait on a side stream + pinned staging from a worker thread) never returned while both
+                # processes' render kernels were still pending; with the host wait it does.  tools/xstream_probe.py shows the
+                # same cross-stream wait on a pending kernel works within one process, so RCCL on one GPU per process is not
+                # expected to need this - but an N-GPU job that hangs loses the whole measurement, and the wait is free.
+                ctx.sync(sp)
                 dist.all_reduce(accum, op=dist.ReduceOp.SUM)          # the one collective: per-GPU spp accumulators
             ctx.resolve_device(accum.data_ptr(), W, H, float(SPP), 1, bgra.data_ptr(), 0, None, sp)
 
@@ -150,6 +161,9 @@ def main():
     os.environ["RT_MI355_JIT"] = "2"          # the documented switch: specialise at the first render of a scene
     if args.warmup == 0:
         ctx.render_path(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, 1, seed=1), 16, 16)
+    if world > 1:                             # the communicator's lazy set-up (RCCL: rings, IPC handles) is one-time too
+        with torch.cuda.stream(stream):
+            dist.all_reduce(torch.zeros(1024, dtype=torch.float32, device="cuda"), op=dist.ReduceOp.SUM)
     for _ in range(args.warmup):
         step()
     fence()
