@@ -268,8 +268,23 @@ def gen_boxes(L4):
     print("box scenes: hit rate", hit.mean(), "box hits", np.isin(which, [0, 1, 2]).mean())
 
 
+def gen_frame01(L):
+    """01 is deterministic: whole frames by the reference's own classes (ref_e1_golden_frame follows Render/TraceTay,
+    01 Main.cpp:324-496) - linear float colour at 196x140, Render's bytes at 196x140 and 784x561, TraceTay call counts."""
+    out = {}
+    for tag, (w, h) in (("196", (196, 140)), ("784", (784, 561))):
+        rgb = np.zeros((h, w, 3), np.float32); bgra = np.zeros((h, w, 4), np.uint8); rays = C.c_ulonglong(0)
+        L.ref_e1_golden_frame(w, h, rgb.ctypes.data_as(C.c_void_p), bgra.ctypes.data_as(C.c_void_p), C.byref(rays))
+        if tag == "196": out["rgb" + tag] = rgb          # the float frame only at the small size (fixture size)
+        out["bgra" + tag] = bgra; out["rays" + tag] = np.uint64(rays.value)
+    np.savez_compressed(os.path.join(OUT, "frame_01.npz"), **out)
+    print("01 frames: rays", int(out["rays196"]), int(out["rays784"]))
+
+
 if __name__ == "__main__":
     import sys
+    if sys.argv[1:] == ["frame01"]:
+        gen_frame01(load(1)); raise SystemExit
     if sys.argv[1:] == ["boxes"]:          # added later: leaves the other fixtures (one shared generator state) untouched
         gen_boxes(load(4)); raise SystemExit
     rng = np.random.default_rng(20201)

@@ -50,3 +50,106 @@ int ref_e1_plane_hit(const float* p, const float* normal, const float* o, const 
     Plane s(Material{}, v(p), v(normal)); V3 nn; int r = s.intersectsRay(raw_ray(o, d), tmin, tmax, t, &nn); if (r) st(n, nn); return r;
 }
 }
+
+// ---- whole-frame golden of 01 -----------------------------------------------------------------------------------------
+// 01 is deterministic, so a frame computed by the reference's own classes pins the CPU restatement BIT FOR BIT at image level.
+// Render / TraceTay live in Main.cpp (not buildable here); the loop below follows them - Main.cpp:324-359 (pixel ray,
+// quantisation) and :372-496 (TraceTay) - and everything it computes with is reference code: the element classes' virtual
+// intersectsRay, Material / LightSource, math::Normalize / Length / Dot / Reflect / Refract / Mix / Clamp and math::Ray.
+#include <limits>
+#include <memory>
+#include <vector>
+#include <cmath>
+namespace golden1 {
+const uint32_t kMaxDepth = 4;      // MAX_RECURSION_DEPTH (Main.cpp:12)
+using Elements = std::vector<std::shared_ptr<SceneElement>>;
+unsigned long long g_rays = 0;
+
+bool trace(const math::Ray& ray, const Elements& elements, const std::vector<LightSource>& lights, float minDistance, float maxDistance, V3* out, uint32_t depth) {
+    ++g_rays;
+    bool hit = false;
+    float nearest = std::numeric_limits<float>::max();
+    V3 normalAtHit = {0.0f, 0.0f, 0.0f};
+    uint32_t index = 0;
+    if (depth <= kMaxDepth)
+        for (uint32_t i = 0; i < elements.size(); i++) {
+            float t; V3 n;
+            if (elements[i]->intersectsRay(ray, minDistance, maxDistance, &t, &n) && t < nearest) { hit = true; nearest = t; normalAtHit = n; index = i; }
+        }
+    if (!out) return hit;
+    if (!hit) { *out = {0.2f, 0.7f, 0.8f}; return false; }
+    const Material& m = elements[index]->getMaterial();
+    const V3 point = ray.getOrigin() + (ray.getDirection() * nearest);
+    V3 primary = {0.0f, 0.0f, 0.0f}, secondary = {0.0f, 0.0f, 0.0f};
+    if (m.primaryToSecondary > 0.0f) {
+        V3 diffuse = {0.0f, 0.0f, 0.0f}, specular = {0.0f, 0.0f, 0.0f};
+        for (const auto& light : lights) {
+            V3 toLight = light.position - point;
+            V3 toLightDir = math::Normalize(toLight);
+            math::Ray shadowRay(point, toLight);
+            if (trace(shadowRay, elements, {}, 0.01f, math::Length(toLight), nullptr, depth + 1)) continue;      // hard shadow
+            diffuse = diffuse + (light.color * std::max(0.0f, math::Dot(toLightDir, normalAtHit)));
+            specular = specular + (light.color * std::pow(std::max(0.0f, math::Dot(math::Reflect(-toLightDir, normalAtHit), -ray.getDirection())), m.shininess));
+        }
+        primary = (diffuse * m.albedo) + (specular * m.specularIntensity);
+    }
+    if (m.primaryToSecondary < 1.0f) {
+        V3 reflection = {0.0f, 0.0f, 0.0f}, refraction = {0.0f, 0.0f, 0.0f};
+        if (m.reflectToRefract > 0.0f) {
+            math::Ray reflected(point, math::Reflect(ray.getDirection(), normalAtHit));
+            trace(reflected, elements, lights, 0.001f, maxDistance, &reflection, depth + 1);
+        }
+        if (m.reflectToRefract < 1.0f) {
+            float eta = m.refractionEta;
+            if (math::Dot(normalAtHit, -ray.getDirection()) < 0.0f) { normalAtHit = -normalAtHit; eta = 1.0f / eta; }
+            math::Ray refracted(point, math::Refract(ray.getDirection(), normalAtHit, eta));
+            trace(refracted, elements, lights, 0.001f, maxDistance, &refraction, depth + 1);
+        }
+        secondary = math::Mix(reflection, refraction, std::max(1.0f - m.reflectToRefract, 0.0f));
+    }
+    *out = math::Mix(primary, secondary, std::max(1.0f - m.primaryToSecondary, 0.0f));
+    return true;
+}
+}  // namespace golden1
+
+extern "C" {
+// The committed scene of 01 (Main.cpp:182-203) at w x h: linear float colour per pixel (rgb, 3 floats), the B,G,R,255 bytes
+// Render would store (bgra) and the number of TraceTay calls.
+void ref_e1_golden_frame(int w, int h, float* rgb, unsigned char* bgra, unsigned long long* rays) {
+    Material redMatte = {V3(1.0f, 0.0f, 0.0f), 0.0f};
+    Material greenMatte = {V3(0.0f, 1.0f, 0.0f), 0.0f};
+    Material whiteMatte = {V3(1.0f, 1.0f, 1.0f), 0.0f};
+    Material redRubber = {V3(0.6f, 0.2f, 0.2f), 0.1f, 16.0f};
+    Material mirror = {V3(0.1f, 0.1f, 0.1f), 1.0f, 512.0f, 0.25f, 1.0f};
+    Material glass = {V3(0.1f, 0.1f, 0.1f), 1.0f, 128.0f, 0.25f, 0.0f, 0.6f};
+    golden1::Elements scene{};
+    scene.push_back(std::make_shared<Plane>(whiteMatte, V3(0.0f, -10.0f, 0.0f), V3(0.0f, 1.0f, 0.0f)));
+    scene.push_back(std::make_shared<Plane>(whiteMatte, V3(0.0f, 10.0f, 0.0f), V3(0.0f, -1.0f, 0.0f)));
+    scene.push_back(std::make_shared<Plane>(whiteMatte, V3(0.0f, 0.0f, -20.0f), V3(0.0f, 0.0f, 1.0f)));
+    scene.push_back(std::make_shared<Plane>(whiteMatte, V3(0.0f, 0.0f, 0.001f), V3(0.0f, 0.0f, -1.0f)));
+    scene.push_back(std::make_shared<Plane>(greenMatte, V3(10.0f, 0.0f, 00.0f), V3(-1.0f, 0.0f, 0.0f)));
+    scene.push_back(std::make_shared<Plane>(redMatte, V3(-10.0f, 0.0f, 00.0f), V3(1.0f, 0.0f, 0.0f)));
+    scene.push_back(std::make_shared<Sphere>(glass, V3(0.0f, -7.0f, -12.0f), 3.0f));
+    scene.push_back(std::make_shared<Sphere>(redRubber, V3(7.5f, -7.0f, -15.0f), 2.0f));
+    scene.push_back(std::make_shared<Sphere>(mirror, V3(-7.5f, -7.0f, -15.0f), 2.0f));
+    std::vector<LightSource> lights{};
+    lights.push_back({V3(0.0f, 8.5f, -10.0f), V3(0.9f, 0.9f, 0.9f)});
+    golden1::g_rays = 0;
+    const float fov = 90.0f, fw = static_cast<float>(w), fh = static_cast<float>(h);
+    const float fovRadians = static_cast<float>(fov / (180.0f / M_PI));
+    for (int j = 0; j < h; j++) for (int i = 0; i < w; i++) {
+        float x = (2.0f * (static_cast<float>(i) + 0.5f) / fw - 1.0f) * tanf(fovRadians / 2.0f) * fw / fh;
+        float y = -(2.0f * (static_cast<float>(j) + 0.5f) / fh - 1.0f) * tanf(fovRadians / 2.0f);
+        math::Ray ray({0.0f, 0.0f, 0.0f}, {x, y, -1.0f});
+        V3 c = {0.0f, 0.0f, 0.0f};
+        golden1::trace(ray, scene, lights, 0.0f, 1000.0f, &c, 0);
+        const size_t p = static_cast<size_t>(j) * w + i;
+        rgb[3 * p] = c.r; rgb[3 * p + 1] = c.g; rgb[3 * p + 2] = c.b;
+        bgra[4 * p] = static_cast<unsigned char>(math::Clamp(c.b, 0.0f, 1.0f) * 255.0f);
+        bgra[4 * p + 1] = static_cast<unsigned char>(math::Clamp(c.g, 0.0f, 1.0f) * 255.0f);
+        bgra[4 * p + 2] = static_cast<unsigned char>(math::Clamp(c.r, 0.0f, 1.0f) * 255.0f);
+        bgra[4 * p + 3] = 255;
+    }
+    *rays = golden1::g_rays;
+}
+}

@@ -6,6 +6,7 @@ size-independent properties.  Tolerances (BASELINE.json north_star):
   03/04 (path traced): identical counter-RNG => identical paths except where a 1-ulp difference flips a
         decision, so per-pixel agreement is a fraction, plus an RMSE bound from the measured sample variance."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -34,6 +35,22 @@ def test_01_default_resolution(ctx, recorded):
     mine = g["bgra"][y:y + png.shape[0], x:x + png.shape[1], 2::-1].astype(int)
     d = np.abs(mine - png)
     assert d.max() <= 1 and (d.max(axis=-1) > 0).mean() < 1e-3
+
+
+def test_01_against_frames_computed_by_the_reference_classes(ctx):
+    """HIP vs tests/golden/frame_01.npz (the reference's own classes, oracle/ref_harness_e1.cpp): identical TraceTay counts,
+    >= 99.9 % of pixels within 1e-4 relative of the reference's float colour, bytes within 1 LSB on < 0.1 % of pixels."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_01.npz"))
+    s, cam, prm = scenes.scene01()
+    g = ctx.render_whitted(s, cam, prm, 196, 140)
+    assert g["rays"] + g["shadow_rays"] == int(gold["rays196"])
+    assert frac_within(g["rgb"], gold["rgb196"], 1e-4) >= 0.999
+    db = np.abs(g["bgra"].astype(int) - gold["bgra196"].astype(int))
+    assert db.max() <= 1 and (db.max(axis=-1) > 0).mean() < 1e-3
+    g = ctx.render_whitted(s, cam, prm, W, H)
+    assert g["rays"] + g["shadow_rays"] == int(gold["rays784"])
+    db = np.abs(g["bgra"].astype(int) - gold["bgra784"].astype(int))
+    assert db.max() <= 1 and (db.max(axis=-1) > 0).mean() < 1e-3
 
 
 @pytest.mark.parametrize("samples", [1, 4, 16, 64])

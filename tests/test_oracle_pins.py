@@ -1,6 +1,8 @@
 """Pins the CPU oracle (oracle/rt_oracle.c) to outputs of the reference itself:
 the README screenshots and the numbers the survey measured on the unmodified reference
 (tests/golden/reference_recorded_outputs.json).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ from rtamd import abi, scenes
 import orc as oracle
 
 W, H = 784, 561
+GOLDEN = lambda name: os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
 
 
 def _crop(img, png, xy):
@@ -27,6 +30,19 @@ def test_01_matches_reference_screenshot_and_ray_count(recorded):
     assert d.max() <= 1
     assert (d > 0).sum() <= 32, (d > 0).sum()
     assert (r["bgra"][:, :, 3] == 255).all()
+
+
+def test_01_is_bit_identical_to_frames_computed_by_the_reference_classes():
+    """tests/golden/frame_01.npz (oracle/gen_golden.py frame01): whole 01 frames computed by the reference's own element
+    classes, math:: and Ray under a loop that follows its Render/TraceTay (oracle/ref_harness_e1.cpp; 01 is deterministic).
+    The oracle reproduces the linear float colours bit for bit, Render's bytes byte for byte, and the TraceTay call count."""
+    g = np.load(GOLDEN("frame_01.npz"))
+    s, cam, prm = scenes.scene01()
+    r = oracle.render_whitted(s, cam, prm, 196, 140, threads=4)
+    assert np.array_equal(r["rgb"], g["rgb196"]) and np.array_equal(r["bgra"], g["bgra196"])
+    assert r["rays"] + r["shadow_rays"] == int(g["rays196"])
+    r = oracle.render_whitted(s, cam, prm, W, H, threads=4)
+    assert np.array_equal(r["bgra"], g["bgra784"]) and r["rays"] + r["shadow_rays"] == int(g["rays784"]) == 968506
 
 
 def test_02_ray_count_and_screenshot(recorded):
