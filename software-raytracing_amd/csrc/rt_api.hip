@@ -623,7 +623,11 @@ rt_ctx* rt_create_multi(const int32_t* device_ids, int32_t n_devices) {
     if (distinct && n_devices > 1 && !(getenv("RT_MI355_NO_RCCL"))) {
         c->rccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!c->rccl_lib) c->rccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!c->rccl_lib || !rccl_bind(c->rccl_lib)) { g_create_error = std::string("rt_create_multi: cannot load RCCL (librccl.so): ") + (dlerror() ? dlerror() : "missing symbols"); rt_destroy(c); return nullptr; }
+        if (!c->rccl_lib || !rccl_bind(c->rccl_lib)) {
+            const char* why = dlerror();                 // one call: dlerror() clears the message it returns
+            g_create_error = std::string("rt_create_multi: cannot load RCCL (librccl.so): ") + (why ? why : "missing symbols");
+            rt_destroy(c); return nullptr;
+        }
         c->comms.assign((size_t)n_devices, nullptr);
         std::vector<int> devs(device_ids, device_ids + n_devices);
         int r = g_rccl.CommInitAll(c->comms.data(), n_devices, devs.data());
@@ -1092,6 +1096,40 @@ int32_t rt_debug_group_share(int32_t s0, int32_t s1, int32_t i, int32_t n, int32
     if (!b || !e || n <= 0 || i < 0 || i >= n || s1 < s0) return RT_ERR_BAD_ARG;
     int bb, ee; share_of(s0, s1, i, n, bb, ee); *b = bb; *e = ee;
     return RT_OK;
+}
+// Self-test of the run-time RCCL binding on one device (the device-group path itself needs distinct GPUs): dlopen + symbols,
+// a one-rank communicator, one grouped out-of-place all-reduce(sum, float32) of n floats, result compared with the input.
+// 0 = ok; 1 = librccl not loadable / symbols missing; 2 = an RCCL call failed; 3 = HIP error; 4 = wrong result.  msg: detail.
+int32_t rt_debug_rccl_selftest(int32_t device, int32_t n, char* msg, int32_t cap) {
+    auto say = [&](const std::string& s) { if (msg && cap > 0) { strncpy(msg, s.c_str(), (size_t)cap - 1); msg[cap - 1] = 0; } };
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { const char* why = dlerror(); say(why ? why : "dlopen failed"); return 1; }
+    if (!rccl_bind(lib)) { say("missing symbols"); return 1; }
+    if (hipSetDevice(device) != hipSuccess || n <= 0) { say("hipSetDevice / n"); return 3; }
+    void* comm = nullptr; int dev = device;
+    int r = g_rccl.CommInitAll(&comm, 1, &dev);
+    if (r != 0) { say(std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); return 2; }
+    std::vector<float> h((size_t)n), back((size_t)n, -1.0f);
+    for (int i = 0; i < n; ++i) h[(size_t)i] = 0.25f * (float)(i % 1021) - 3.0f;
+    float *a = nullptr, *b = nullptr; hipStream_t st = nullptr;
+    int rc = 0;
+    if (hipMalloc((void**)&a, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&b, (size_t)n * 4) != hipSuccess || hipStreamCreate(&st) != hipSuccess ||
+        hipMemcpyAsync(a, h.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipMemsetAsync(b, 0xFF, (size_t)n * 4, st) != hipSuccess) { say("HIP set-up"); rc = 3; }
+    if (!rc) {
+        r = g_rccl.GroupStart();
+        if (r == 0) r = g_rccl.AllReduce(a, b, (size_t)n, kNcclFloat32, kNcclSum, comm, st);
+        const int r2 = g_rccl.GroupEnd();
+        if (r != 0 || r2 != 0) { say(std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r ? r : r2)); rc = 2; }
+    }
+    if (!rc && (hipMemcpyAsync(back.data(), b, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) { say("HIP read-back"); rc = 3; }
+    if (!rc && memcmp(back.data(), h.data(), (size_t)n * 4) != 0) { say("all-reduce of one rank did not reproduce its input"); rc = 4; }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    (void)g_rccl.CommDestroy(comm);
+    if (!rc) say("ok");
+    return rc;
 }
 int32_t rt_debug_set_flags(rt_ctx* c, int32_t f) { if (!c) return RT_ERR_BAD_ARG; c->debug_flags = f; return RT_OK; }
 int32_t rt_debug_set_regen_threshold(rt_ctx* c, int32_t n) { if (!c) return RT_ERR_BAD_ARG; c->regen_threshold_override = n; return RT_OK; }

@@ -730,3 +730,14 @@ def test_progressive_frame_on_device_equals_one_shot(ctx):
                 c.progressive_pass(1)
     finally:
         groups[1].close()
+
+
+def test_rccl_binding_selftest(ctx):
+    """The device group binds RCCL at run time (dlopen, rccl.h signatures and enum values restated in rt_api.hip); a group of
+    distinct GPUs cannot be formed on a one-GPU box, so this exercises the binding itself: a one-rank communicator and one
+    grouped out-of-place all-reduce(sum, float32) must reproduce its input."""
+    L = lib.load()
+    L.rt_debug_rccl_selftest.argtypes = [C.c_int32, C.c_int32, C.c_char_p, C.c_int32]
+    msg = C.create_string_buffer(256)
+    rc = L.rt_debug_rccl_selftest(0, 1 << 20, msg, 256)
+    assert rc == 0, (rc, msg.value.decode())
