@@ -70,7 +70,7 @@ struct HostScene {
         {
             BvhItem it{}; it.ref = (uint32_t)start | (uint32_t)dtype; it.bounded = true;
             const float4* S = slots.data() + slots.size() - n_f4;
-            if (dtype == PRIM_SPHERE) {
+            if (is_sphere_type(dtype)) {
                 const float c[3] = {S[0].x, S[0].y, S[0].z}, r = sqrtf(S[0].w) * 1.000001f;
                 for (int a = 0; a < 3; ++a) { it.lo[a] = c[a] - r; it.hi[a] = c[a] + r; }
             } else if (dtype == PRIM_RECT) {
@@ -201,7 +201,8 @@ TriBasis tri_basis(const float* f) {
 }
 
 // Validates rt_scene and builds the device layout documented in rt_device.h.
-int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/, HostScene& H) {
+// tmin: the path render's tMin (spheres of radius > RT_BIG_SPHERE_RATIO * tmin get the refined root, rt_device.h); unused for Whitted scenes
+int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/, float tmin, HostScene& H) {
     if (!s || s->n_prims < 0 || s->n_materials < 0 || s->n_lights < 0) return fail(c, RT_ERR_BAD_ARG, "scene: null or negative count");
     if ((s->n_prims && !s->prims) || (s->n_materials && !s->materials) || (s->n_lights && !s->lights))
         return fail(c, RT_ERR_BAD_ARG, "scene: null array with non-zero count");
@@ -251,6 +252,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
             bool wide = false;
             switch (P.type) {
             case RT_PRIM_SPHERE: {
+                if (variant != 0 && fabsf(f[3]) > RT_BIG_SPHERE_RATIO * tmin) dtype = PRIM_SPHERE_BIG;
                 G = f4(f[0], f[1], f[2], f[3] * f[3]);
                 A = f4(f[0], f[1], f[2], (P.flags & RT_PRIM_FLAG_FLIP_NORMALS) ? -1.0f : 1.0f);
                 break; }
@@ -427,26 +429,27 @@ int upload_scene(rt_ctx* c, const HostScene& H, hipStream_t st, DevScene& D) {
 
 // compile_scene + (optional) build_bvh + upload_scene behind a one-entry cache keyed by the scene's bytes: progressive and
 // repeated renders of one scene (the BVH build of the stress scene alone is 20 ms) pay for it once.
-uint64_t scene_key(const rt_scene* s, int variant, int accel) {
+uint64_t scene_key(const rt_scene* s, int variant, int accel, float tmin) {
     uint64_t h = 1469598103934665603ULL;
     auto mix = [&](const void* p, size_t n) {
         const unsigned char* b = (const unsigned char*)p; size_t i = 0;
         for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ULL; }
         for (; i < n; ++i) h = (h ^ b[i]) * 1099511628211ULL;
     };
-    const int32_t head[5] = {variant, accel, s->n_prims, s->n_materials, s->n_lights};
+    int32_t tmin_bits; memcpy(&tmin_bits, &tmin, 4);
+    const int32_t head[6] = {variant, accel, s->n_prims, s->n_materials, s->n_lights, tmin_bits};
     mix(head, sizeof head);
     if (s->n_prims > 0 && s->prims) mix(s->prims, (size_t)s->n_prims * sizeof(rt_prim));
     if (s->n_materials > 0 && s->materials) mix(s->materials, (size_t)s->n_materials * sizeof(rt_material));
     if (s->n_lights > 0 && s->lights) mix(s->lights, (size_t)s->n_lights * sizeof(rt_light));
     return h;
 }
-int prepare_scene(rt_ctx* c, const rt_scene* scene, int variant, bool accel, hipStream_t st, const HostScene*& H, DevScene& D) {
+int prepare_scene(rt_ctx* c, const rt_scene* scene, int variant, float tmin, bool accel, hipStream_t st, const HostScene*& H, DevScene& D) {
     if (!scene || scene->n_prims < 0 || scene->n_materials < 0 || scene->n_lights < 0 || (scene->n_prims && !scene->prims) ||
         (scene->n_materials && !scene->materials) || (scene->n_lights && !scene->lights)) {
-        HostScene tmp; return compile_scene(c, scene, variant, tmp);      // reports the error
+        HostScene tmp; return compile_scene(c, scene, variant, tmin, tmp);      // reports the error
     }
-    const uint64_t key = scene_key(scene, variant, accel ? 1 : 0);
+    const uint64_t key = scene_key(scene, variant, accel ? 1 : 0, tmin);
     const size_t nb_p = (size_t)scene->n_prims * sizeof(rt_prim), nb_m = (size_t)scene->n_materials * sizeof(rt_material), nb_l = (size_t)scene->n_lights * sizeof(rt_light);
     bool hit = c->cache_valid && c->cache_key == key && c->cache_stream == st && c->cache_bytes.size() == nb_p + nb_m + nb_l;
     if (hit) {   // a 64-bit hash can collide: the cached blob is only reused for the very same records
@@ -456,7 +459,7 @@ int prepare_scene(rt_ctx* c, const rt_scene* scene, int variant, bool accel, hip
     if (!hit) {
         c->cache_valid = false;
         c->cache_H = HostScene();
-        int rc = compile_scene(c, scene, variant, c->cache_H);
+        int rc = compile_scene(c, scene, variant, tmin, c->cache_H);
         if (rc) return rc;
         if (accel) {
             build_bvh(c->cache_H.items, c->cache_H.bvh);
@@ -702,7 +705,7 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     if (noalloc) {
         if (accel) return fail(c, RT_ERR_UNSUPPORTED, "rt_path_accumulate_device_noalloc: brute force only (RT_OPT_ACCEL must be RT_ACCEL_NONE)");
         if (!c->scratch_dev) return fail(c, RT_ERR_HIP, "rt_path_accumulate_device_noalloc: no scratch array on this device");
-        if ((rc = compile_scene(c, scene, p->variant, na_H))) return rc;
+        if ((rc = compile_scene(c, scene, p->variant, p->t_min, na_H))) return rc;
         const BlobLayout L = blob_layout(na_H);
         if (L.total > RT_NOALLOC_SCENE_BYTES)
             return fail(c, RT_ERR_TOO_LARGE, "rt_path_accumulate_device_noalloc: flattened scene is " + std::to_string(L.total) + " bytes, the fixed scratch holds " +
@@ -710,7 +713,7 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
         if ((rc = fill_and_upload_scene(c, na_H, L, st, D, (char*)c->h_stage_na, c->scratch_dev, c->ev_scene_use_na))) return rc;
         Hp = &na_H;
         counters = reinterpret_cast<unsigned long long*>(c->scratch_dev + RT_NOALLOC_SCENE_BYTES);
-    } else if ((rc = prepare_scene(c, scene, p->variant, accel, st, Hp, D))) return rc;
+    } else if ((rc = prepare_scene(c, scene, p->variant, p->t_min, accel, st, Hp, D))) return rc;
     const HostScene& H = *Hp;
 
     PathArgs A{};
@@ -794,7 +797,7 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
         if (cam->position[k] != 0.0f || cam->orientation_deg[k] != 0.0f) return fail(c, RT_ERR_BAD_ARG, "examples 01/02 have a fixed camera: position/orientation must be zero");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     const HostScene* Hp = nullptr; DevScene D;
-    if ((rc = prepare_scene(c, scene, 0, false, st, Hp, D))) return rc;
+    if ((rc = prepare_scene(c, scene, 0, 0.0f, false, st, Hp, D))) return rc;
     const HostScene& H = *Hp;
     WhittedArgs A{};
     A.width = width; A.height = height; A.max_depth = p->max_depth; A.shadow_samples = p->shadow_samples; A.seed = p->seed;
@@ -1031,10 +1034,11 @@ int32_t rt_debug_last_whitted_kernel(const rt_ctx* c) { return c ? c->last_whitt
 // variant 3 / 4: the path kernels; 2: the 02 kernel (a Whitted scene)
 int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, int32_t cap) {
     HostScene H;
-    int rc = compile_scene(nullptr, scene, (variant & 7) == RT_JIT_WHITTED_SOFT ? 0 : (variant & 7), H);
+    const float tmin = (variant & 7) == 3 ? 0.001f : 0.01f;       // the examples' constants (rt_path_params_default)
+    int rc = compile_scene(nullptr, scene, (variant & 7) == RT_JIT_WHITTED_SOFT ? 0 : (variant & 7), tmin, H);
     if (rc) return rc;
     std::string n;
-    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, (variant & 7) == 3 ? 0.001f : 0.01f, 1000.0f, (variant & 8) != 0, n);
+    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, tmin, 1000.0f, (variant & 8) != 0, n);
     if (note && cap > 0) { strncpy(note, n.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
     return fn ? 1 : 0;
 }
@@ -1043,7 +1047,7 @@ int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, i
 // RT_BVH_LEAF entries.  out[0..4] = {nodes, leaf entries, unbounded slots, depth, slots}.  Returns 0, or the number of violations.
 int32_t rt_debug_bvh_probe(const rt_scene* scene, int32_t variant, int32_t* out) {
     HostScene H;
-    int rc = compile_scene(nullptr, scene, variant, H);
+    int rc = compile_scene(nullptr, scene, variant, variant == 3 ? 0.001f : 0.01f, H);
     if (rc) return rc;
     std::vector<BvhItem> items = H.items;
     build_bvh(items, H.bvh);

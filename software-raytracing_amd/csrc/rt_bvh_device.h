@@ -24,12 +24,12 @@ __device__ __forceinline__ void bvh_take(BvhHit& H, bool ok, float t, uint32_t q
 __device__ __forceinline__ void bvh_test(const SceneMem<false> M, uint32_t ref, f3 o, f3 d, f3 inv_d, float tmin, float tminp, BvhHit& H) {
     const uint32_t q = ref & ~63U;
     const int type = (int)(ref & 7U);
-    if (type == PRIM_SPHERE) {
+    if (is_sphere_type(type)) {
         float4 g = M.ld4(q);
         f3 co = F3(g) - o;
         float b = dot(d, co);
         float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, -g.w)));
-        float s = sqrt_fast(fmaf(b, b, -c));
+        float s = type == PRIM_SPHERE_BIG ? sqrt_refined(fmaf(b, b, -c)) : sqrt_fast(fmaf(b, b, -c));      // as in closest_hit_runs: same bits
         float t1 = b - s, t2 = b + s;
         bool near_behind = t1 < tmin;
         float tc = near_behind ? t2 : t1;
@@ -37,7 +37,7 @@ __device__ __forceinline__ void bvh_test(const SceneMem<false> M, uint32_t ref, 
         bvh_take(H, ge, tc, q);
         const bool cand = ge & near_behind & (q > H.steal);
         H.steal = cand ? q : H.steal; H.steal_t = cand ? tc : H.steal_t;
-    } else if (type >= PRIM_AAPLANE_X) {
+    } else if (is_aaplane_type(type)) {
         const float oa = type == PRIM_AAPLANE_X ? o.x : (type == PRIM_AAPLANE_Y ? o.y : o.z);
         const float ia = type == PRIM_AAPLANE_X ? inv_d.x : (type == PRIM_AAPLANE_Y ? inv_d.y : inv_d.z);
         float t = (M.ld1(q) - oa) * ia;

@@ -56,7 +56,19 @@ __device__ __forceinline__ Scn scn_over(const DevScene& S, const float4* base) {
     return v;
 }
 
-enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLANE_X = 4, PRIM_AAPLANE_Y = 5, PRIM_AAPLANE_Z = 6 };
+enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLANE_X = 4, PRIM_AAPLANE_Y = 5, PRIM_AAPLANE_Z = 6, PRIM_SPHERE_BIG = 7 };
+// PRIM_SPHERE_BIG: a sphere whose radius exceeds RT_BIG_SPHERE_RATIO x tMin (03's ground sphere: r = 100, tMin = 0.001).  Same
+// slot, same test, but the square root of the discriminant is refined (sqrt_refined below).  Why: the hardware square root is
+// good to 1 ulp but not unbiased; through t = b -+ s that puts hit points preferentially a few 1e-7 of the distance INSIDE the
+// sphere, where the next ray's far root lands just above tMin ("acne": a false self-hit).  A ray leaving the surface at cos(theta)
+// from a depth h self-hits when cos(theta) < h/tMin - tMin/(2r): never for small spheres, often for large ones.  The reference's
+// correctly rounded sqrtf has no such bias; measured against it (scene queries per sample at tMin = 0.001, one sphere seen at a
+// grazing angle, tools/big_sphere_check.py): r = 100: +1.6e-3 with the hardware root, +1.5e-4 refined; r = 1000: +1.4e-2 vs -3.7e-4;
+// r = 10: +8e-7 vs -1.1e-4 - so the refined root is used from r/tMin = 3e4 up (03: the ground sphere only; 04 and the stress
+// scene: none).
+#define RT_BIG_SPHERE_RATIO 30000.0f
+__device__ __host__ inline bool is_sphere_type(int t) { return t == PRIM_SPHERE || t == PRIM_SPHERE_BIG; }
+__device__ __host__ inline bool is_aaplane_type(int t) { return t >= PRIM_AAPLANE_X && t <= PRIM_AAPLANE_Z; }
 enum { MAT_PHONG = 0, MAT_DIFFUSE = 1, MAT_METAL = 2, MAT_DIELECTRIC = 3, MAT_LIGHT = 4, MAT_NONE = 5 };
 
 // ---- float3 -----------------------------------------------------------------------------------
@@ -78,6 +90,12 @@ __device__ __forceinline__ f3 sel(bool c, f3 a, f3 b) { return F3(c ? a.x : b.x,
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+// sqrt to ~0.5 ulp without a second transcendental: one Newton step on s = x*rsq(x).  x < 0 -> NaN (as sqrt), x = 0 -> 0
+// (the 2e-38 keeps rsq finite there and vanishes in x + 2e-38 for every x that matters).
+__device__ __forceinline__ float sqrt_refined(float x) {
+    const float r = rsq_fast(x + 2e-38f), s = x * r;
+    return fmaf(fmaf(-s, s, x), 0.5f * r, s);
+}
 
 // math::Normalize (Common/Math.hpp:233-238): zero vector stays zero.
 __device__ __forceinline__ f3 normalize(f3 v) {
@@ -194,13 +212,14 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
             run = runs[r + 1];     // prefetch (the section is padded by one record)
         }
         if (LDS) asm volatile("" : "+v"(q), "+v"(best), "+v"(closest));   // one definition point per run for the carried values
-        if (type == PRIM_SPHERE) {
+        if (is_sphere_type(type)) {
+            const bool big = type == PRIM_SPHERE_BIG;      // wave-uniform (a run descriptor)
             // Ray::intersectsSphere (Common/Ray.hpp:94-137).  Roots t1 <= t2; "a root below tMin becomes tMax" (:127-128):
             // a ray that starts inside a sphere whose far root lies beyond tMax still reports a hit AT tMax (:129-134):
             // the element wins, the distance stays.  disc < 0 gives NaN roots, which fail every compare.
 #define RT_SPHERE_DISC(G, B, DISC) f3 co_ = F3(G) - o; B = dot(d, co_); \
                 DISC = fmaf(B, B, -fmaf(co_.z, co_.z, fmaf(co_.y, co_.y, fmaf(co_.x, co_.x, -(G).w))))
-#define RT_SPHERE_ROOTS(B, DISC, Q) { float s = sqrt_fast(DISC); float t1 = (B) - s, t2 = (B) + s; \
+#define RT_SPHERE_ROOTS(B, DISC, Q) { float s = big ? sqrt_refined(DISC) : sqrt_fast(DISC); float t1 = (B) - s, t2 = (B) + s; \
                 bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; bool ge = tc >= tmin, le = tc <= closest; \
                 closest = (ge & le) ? tc : closest; best = (ge & (near_behind | le)) ? (Q) : best; }
             int i = 0;
@@ -229,7 +248,7 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
             }
 #undef RT_SPHERE_DISC
 #undef RT_SPHERE_ROOTS
-        } else if (type >= PRIM_AAPLANE_X) {
+        } else if (is_aaplane_type(type)) {
             // Ray::intersectsPlane (Ray.hpp:223-249) for a normal +-e_axis: n.p0 - n.o = +-(p0_a - o_a), d.n = +-d_a, so
             // t = (p0_a - o_a) * (1/d_a), 1/d shared by all such planes of the ray.  tminp = max(tMin, smallest positive
             // float) folds "t > 0 && t >= tMin" into one compare; d_a = 0 gives inf/NaN, which fails the range test.

@@ -79,13 +79,13 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
             const float4* g = &slots[q];
             const std::string K = std::to_string(q * 16 + SLOT_BYTES) + "U";
             const std::string take = "closest = hit ? t : closest; best = hit ? " + K + " : best; }\n";
-            if (run.x == PRIM_SPHERE) {
+            if (is_sphere_type(run.x)) {
                 s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
                 s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
-                s += "      float s = sqrt_fast(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;\n";
+                s += std::string("      float s = ") + (run.x == PRIM_SPHERE_BIG ? "sqrt_refined" : "sqrt_fast") + "(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;\n";
                 s += "      bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; bool ge = tc >= tmin, le = tc <= closest;\n";
                 s += "      closest = (ge & le) ? tc : closest; best = (ge & (near_behind | le)) ? " + K + " : best; }\n";
-            } else if (run.x >= PRIM_AAPLANE_X) {
+            } else if (is_aaplane_type(run.x)) {
                 const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
                 s += "    { float t = (" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + "; bool hit = (t >= tminp) & (t <= closest); " + take;
             } else if (run.x == PRIM_PLANE) {
@@ -116,12 +116,12 @@ std::string gen_any_hit(const std::vector<float4>& slots, const std::vector<int4
     for (const int4& run : sruns) {
         for (int i = 0; i < run.z; ++i) {
             const float4* g = &slots[q];
-            if (run.x == PRIM_SPHERE) {
+            if (is_sphere_type(run.x)) {
                 s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
                 s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
-                s += "      float s = sqrt_fast(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;\n";
+                s += std::string("      float s = ") + (run.x == PRIM_SPHERE_BIG ? "sqrt_refined" : "sqrt_fast") + "(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;\n";
                 s += "      bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; occ |= (tc >= tmin) & (near_behind | (tc <= tmax)); }\n";
-            } else if (run.x >= PRIM_AAPLANE_X) {
+            } else if (is_aaplane_type(run.x)) {
                 const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
                 s += "    { float t = (" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + "; occ |= (t >= tminp) & (t <= tmax); }\n";
             } else if (run.x == PRIM_PLANE) {
@@ -171,10 +171,10 @@ bool sphere_interior_is_empty(const std::vector<float4>& slots, const std::vecto
             const size_t step = (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
             if (q != q0) {
                 double dist;      // a lower bound of the distance from the sphere's centre to the other primitive's surface
-                if (run.x == PRIM_SPHERE) {
+                if (is_sphere_type(run.x)) {
                     const double dx = g[0].x - S.x, dy = g[0].y - S.y, dz = g[0].z - S.z;
                     dist = std::fabs(std::sqrt(dx * dx + dy * dy + dz * dz) - std::sqrt((double)g[0].w));
-                } else if (run.x >= PRIM_AAPLANE_X) {
+                } else if (is_aaplane_type(run.x)) {
                     const double c = run.x == PRIM_AAPLANE_X ? S.x : run.x == PRIM_AAPLANE_Y ? S.y : S.z;
                     dist = std::fabs(c - g[0].x);
                 } else if (run.x == PRIM_PLANE) {
@@ -207,12 +207,12 @@ std::string gen_closest_hit_v2(const std::vector<float4>& slots, const std::vect
         for (int i = 0; i < run.z; ++i) {
             const float4* g = &slots[q];
             const std::string K = std::to_string(q * 16 + SLOT_BYTES) + "U";
-            if (skip && ((run.x == PRIM_SPHERE && strchr(skip, 's')) || (run.x >= PRIM_AAPLANE_X && strchr(skip, 'a')) || ((run.x == PRIM_RECT || run.x == PRIM_TRI) && strchr(skip, 'r')))) {
+            if (skip && ((is_sphere_type(run.x) && strchr(skip, 's')) || (is_aaplane_type(run.x) && strchr(skip, 'a')) || ((run.x == PRIM_RECT || run.x == PRIM_TRI) && strchr(skip, 'r')))) {
                 q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4; continue; }
-            if (run.x == PRIM_SPHERE) {
+            if (is_sphere_type(run.x)) {
                 s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
                 s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
-                s += "      float s = sqrt_fast(fmaf(b, b, -c));\n";
+                s += std::string("      float s = ") + (run.x == PRIM_SPHERE_BIG ? "sqrt_refined" : "sqrt_fast") + "(fmaf(b, b, -c));\n";
                 if (sphere_interior_is_empty(slots, sruns, q, tmin, tmax)) {
                     s += "      float t1 = b - s; uint32_t k = __float_as_uint(t1 < " + lit(tmin) + " ? b + s : t1) - " + C + ";\n";
                     s += "     " + take(K);
@@ -221,7 +221,7 @@ std::string gen_closest_hit_v2(const std::vector<float4>& slots, const std::vect
                 s += "      uint32_t k1 = __float_as_uint(b - s) - " + C + ", k2 = __float_as_uint(b + s) - " + C + "; uint32_t k = k1 < k2 ? k1 : k2;\n";
                 // the tMax rule: near root behind tMin, far root ahead (finite) but not accepted: the element wins, the distance stays
                     s += "      bool a = k <= ck; bool w = a | ((k1 > " + hex(J.vmax) + ") & (k2 <= " + hex(J.vmax) + ")); ck = a ? k : ck; best = w ? " + K + " : best; }\n";
-            } else if (run.x >= PRIM_AAPLANE_X) {
+            } else if (is_aaplane_type(run.x)) {
                 const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
                 s += "    { uint32_t k = __float_as_uint((" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + ") - " + C + ";" + take(K);
             } else if (run.x == PRIM_PLANE) {

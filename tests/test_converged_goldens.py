@@ -41,7 +41,10 @@ def _check(name, img, n, which, rays_per_sample=None, gamma=True, mean_rtol=0.01
     assert rmse <= bound, (rmse, bound)
     assert np.allclose(ratio, 1.0, rtol=mean_rtol, atol=0), ratio
     if rays_per_sample is not None:
-        assert abs(rays_per_sample - rps) <= 0.004 * rps, (rays_per_sample, rps)
+        # scene queries per sample: a path statistic no colour bound sees.  At the goldens' own sample counts the noise of the
+        # ratio is ~1e-4; 5e-4 there caught the hardware square root's bias on 03's ground sphere (+1.1e-3, rt_device.h)
+        tol = 5e-4 if n >= 8192 else 0.004
+        assert abs(rays_per_sample - rps) <= tol * rps, (rays_per_sample, rps, rays_per_sample / rps - 1.0)
 
 
 def _scene(which, spp, seed):

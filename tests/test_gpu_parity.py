@@ -741,3 +741,28 @@ def test_rccl_binding_selftest(ctx):
     msg = C.create_string_buffer(256)
     rc = L.rt_debug_rccl_selftest(0, 1 << 20, msg, 256)
     assert rc == 0, (rc, msg.value.decode())
+
+
+@pytest.mark.parametrize("radius", [10.0, 100.0, 1000.0])
+def test_large_sphere_self_intersections_match_the_reference_arithmetic(ctx, radius):
+    """One large sphere seen at a grazing angle (03's ground is r = 100 at tMin = 0.001).  In float the hit point of a far, large
+    sphere lies a few 1e-7 of the distance inside or outside it, and a ray leaving from inside at a grazing angle finds the far
+    root just above tMin: a false self-hit, frequent in the reference itself (a convex sphere alone would give < 2 queries per
+    sample; r = 1000 gives 2.13).  How often depends on the rounding of the roots: the hardware square root's bias made HIP trace
+    +1.6e-3 (r = 100) / +1.4e-2 (r = 1000) more queries than the reference's arithmetic (the oracle); spheres of radius
+    > 3e4 tMin now take a refined root (rt_device.h).  Every kernel form, 1024 spp, equal seeds."""
+    s = scenes.Scene(); s.sphere(s.diffuse((0.8, 0.8, 0.0)), (0, -0.5 - radius, -1.0), radius)
+    cam = scenes.camera(50.0, (-2.0, 1.5, 1.0), (-30.0, -42.0, 0.0))
+    prm = scenes.path_params(abi.RT_PATH_SKY, 1024, seed=1)
+    o = oracle.render_path(s, cam, prm, 196, 140, threads=8)
+    rays = set()
+    for flags, accel in ((8, 0), (16, 0), (8, 1)):
+        ctx.set_debug_flags(flags); ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_BVH if accel else abi.RT_ACCEL_NONE)
+        try:
+            g = ctx.render_path(s, cam, prm, 196, 140)
+        finally:
+            ctx.set_debug_flags(0); ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_NONE)
+        rays.add(g["rays"])
+    assert len(rays) == 1                                       # generic, specialised and BVH kernels: the same paths
+    assert abs(g["rays"] / o["rays"] - 1.0) <= 5e-4, g["rays"] / o["rays"] - 1.0
+    assert abs(g["rgb"].mean() / (o["sum"] / 1024).mean() - 1.0) <= 5e-4

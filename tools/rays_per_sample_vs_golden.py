@@ -1,0 +1,13 @@
+import os, sys
+sys.path.insert(0, "software-raytracing_amd")
+import numpy as np
+from rtamd import abi, lib, scenes
+ctx = lib.Context()
+for name, fn in (("03", scenes.scene03), ("04", scenes.scene04)):
+    g = np.load(f"tests/golden/converged_{name}.npz")
+    for seed in (1, 2):
+        s, cam, prm = fn(16384, seed=seed)
+        r = ctx.render_path(s, cam, prm, 196, 140)
+        rps = r["rays"] / r["samples"]
+        print(name, "seed", seed, "HIP rays/sample", rps, "reference", float(g["rays_per_sample"]), "rel diff", rps / float(g["rays_per_sample"]) - 1,
+              "mean HIP", r["rgb"].mean(axis=(0, 1)), "ref", g["mean"].mean(axis=(0, 1)), flush=True)
