@@ -1,3 +1,4 @@
+"""HIP vs the oracle on the config 5 scene (18,194 primitives, 04 estimator) at equal seeds: scene queries per sample and mean colour."""
 import os, sys, time
 ROOT = os.getcwd()
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))

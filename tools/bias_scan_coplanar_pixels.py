@@ -1,3 +1,4 @@
+"""The pixels behind the coplanar-surfaces deviation (a glass box resting exactly on the floor plane): 1 spp, HIP vs oracle, by depth limit."""
 import os, sys
 ROOT = os.getcwd()
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -1,3 +1,4 @@
+"""02: per-pixel comparison of the HIP frame with the oracle at one seed (where the few differing pixels are)."""
 import os, sys
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))

@@ -1,3 +1,4 @@
+"""Config 5 scene: how often HIP and the oracle trace the same path per pixel, by sphere count (ill-conditioned discriminants of far small spheres)."""
 import sys, os
 sys.path.insert(0,'software-raytracing_amd'); sys.path.insert(0,'oracle')
 import numpy as np, torch

@@ -1,3 +1,4 @@
+"""Stress scene at reduced counts: per-pixel agreement of the global-memory kernel with the oracle."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))

@@ -1,3 +1,4 @@
+"""Sums every counter of a rocprofv3 --pmc output directory over the path kernels' dispatches: python3 tools/pmc_summary.py <dir> ..."""
 import csv, collections, sys, glob
 for d in sys.argv[1:]:
     agg = collections.defaultdict(float)

@@ -1,3 +1,4 @@
+"""Scene queries per sample of the HIP kernels against tests/golden/converged_0{3,4}.npz (the reference's own code) at the goldens' sample count."""
 import os, sys
 sys.path.insert(0, "software-raytracing_amd")
 import numpy as np

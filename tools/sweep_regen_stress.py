@@ -1,3 +1,4 @@
+"""Regeneration-threshold sweep on the stress scene (many primitives: an iteration costs far more than the camera code)."""
 import os, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))

@@ -1,3 +1,4 @@
+"""Per-pixel diagnostics: scene-query counts of one pixel, HIP (debug flag 4) vs the oracle."""
 import sys, ctypes as C, math
 import torch
 import numpy as np
