@@ -59,7 +59,8 @@ __device__ __forceinline__ Scn scn_over(const DevScene& S, const float4* base) {
 enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLANE_X = 4, PRIM_AAPLANE_Y = 5, PRIM_AAPLANE_Z = 6, PRIM_SPHERE_BIG = 7 };
 // PRIM_SPHERE_BIG: a sphere whose radius exceeds RT_BIG_SPHERE_RATIO x tMin (03's ground sphere: r = 100, tMin = 0.001).  Same
 // slot, same test, but the square root of the discriminant is refined (sqrt_refined below).  Why: the hardware square root is
-// good to 1 ulp but not unbiased; through t = b -+ s that puts hit points preferentially a few 1e-7 of the distance INSIDE the
+// good to 1 ulp but not unbiased (v_sqrt_f32: 14.9 % of results one ulp LOW, 0.01 % high, mean -0.149 ulp; the refined form:
+// correctly rounded on all 2^24 samples - tools/sqrt_bias.hip, profiles/r02_sqrt_bias.txt); through t = b -+ s that puts hit points preferentially a few 1e-7 of the distance INSIDE the
 // sphere, where the next ray's far root lands just above tMin ("acne": a false self-hit).  A ray leaving the surface at cos(theta)
 // from a depth h self-hits when cos(theta) < h/tMin - tMin/(2r): never for small spheres, often for large ones.  The reference's
 // correctly rounded sqrtf has no such bias; measured against it (scene queries per sample at tMin = 0.001, one sphere seen at a
