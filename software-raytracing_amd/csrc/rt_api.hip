@@ -503,6 +503,14 @@ int pick_slices(int width, int height, int n_samples) {
     long long target = 4LL * 256 * 2048;
     int s = (int)((target + pixels - 1) / pixels);
     if (s < 1) s = 1;
+    // long frames: a block that renders all samples of its tile lives for tens of milliseconds (17 ms at 4K / 1024 spp) and the
+    // launch ends with most CUs waiting for the last of them.  At most 128 samples per block, up to 8 slices and 2 GiB of
+    // partial images: 268.5 -> 263.9 ms on the headline frame (tools/slices_probe.sh); no effect at 256 spp, and on short
+    // frames more slices only cost (03 at 1080p / 256 spp: 6.2 ms with 2 slices, 6.8 with 8)
+    int by_length = (n_samples + 127) / 128;
+    if (by_length > 8) by_length = 8;
+    while (by_length > s && (long long)by_length * pixels * 16 > (2LL << 30)) --by_length;
+    if (by_length > s) s = by_length;
     if (s > n_samples) s = n_samples;
     if (s > 64) s = 64;
     return s < 1 ? 1 : s;
@@ -730,6 +738,10 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     A.px = cam->position[0]; A.py = cam->position[1]; A.pz = cam->position[2];
     int n_samples = s1 - s0;
     int slices = n_samples > 0 ? pick_slices(width, height, n_samples) : 1;
+    if (const char* e = getenv("RT_MI355_SLICES")) {      // experiment switch: sample slices per frame (shorter blocks, a shorter tail; costs the partial images)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64 && n_samples > 0) slices = v < n_samples ? v : n_samples;
+    }
     size_t npx = (size_t)width * height;
     if (noalloc) {   // the partial images must fit the fixed scratch: fewer slices, or none (the kernel then writes d_accum directly)
         const size_t fit = RT_NOALLOC_PARTIAL_BYTES / (npx * sizeof(float4));
