@@ -219,7 +219,7 @@ def main():
                        "samples_per_step": W * H * SPP, "rays_per_step": rays_step, "samples_per_sec": W * H * SPP * args.steps / dt,
                        "parallelism": (f"sample-range x{world}, one all-reduce(sum) of the {W * H * 16 / 1e6:.1f} MB accumulator" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")) if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": traffic, "traffic_source": ("profiles/r02_pmc_hbm_traffic.json: separate rocprofv3 --pmc passes of this command, not this run" if traffic is not None else None), "kernel": {2: "k_path_jit (scene-specialised rt::path_body<4, true>, hiprtc)", 1: "rt::k_path<4, true>", 0: "rt::k_path_tiled<4>"}.get(ctx.last_path_kernel()[0], "?"), "kernel_ms": k_ms, "kernel_ms_steps": [round(x, 3) for x in kernel_ms], "flops_per_ray": fpr, "rays_per_launch": rays,
+                         "traffic": traffic, "traffic_source": ("profiles/r02_pmc_hbm_traffic.json: separate rocprofv3 --pmc passes of this command, not this run; 8 partial images (sample slices, DESIGN.md 5) on purpose: algorithmic bytes are 16 B/pixel = 132.7 MB" if traffic is not None else None), "kernel": {2: "k_path_jit (scene-specialised rt::path_body<4, true>, hiprtc; kernel_ms includes k_sum_slices, 0.2 ms)", 1: "rt::k_path<4, true>", 0: "rt::k_path_tiled<4>"}.get(ctx.last_path_kernel()[0], "?"), "kernel_ms": k_ms, "kernel_ms_steps": [round(x, 3) for x in kernel_ms], "flops_per_ray": fpr, "rays_per_launch": rays,
                          "note": "FP32 VALU-bound path (no MFMA, negligible HBM traffic): algorithmic FLOPs/ray x rays / kernel time vs the FP32 vector peak"},
         }
         if world == 1 and not args.no_cpu_baseline:
