@@ -12,6 +12,7 @@ import argparse
 import ctypes as C
 import multiprocessing as mp
 import os
+import sys
 import time
 
 import numpy as np
@@ -23,8 +24,12 @@ DP = C.POINTER(C.c_double)
 
 
 def _band(args):
-    which, spp, y0, y1, rank = args
+    which, spp, y0, y1, rank = args[:5]
+    W, H = args[5:7] if len(args) > 5 else (globals()['W'], globals()['H'])      # spawned workers do not see a changed module global
     time.sleep(0.007 * rank)                       # distinct clock seeds (milliseconds) per process
+    shadow = 16
+    if which.startswith("02s"):                    # 02 at another shadow-sample count (BASELINE config 2's sweep): "02s64"
+        shadow, which = int(which[3:]), "02"
     n = {"02": 2, "03": 3, "03r": 3, "04": 4}[which]
     L = C.CDLL(os.path.join(HERE, "_ref", f"libref_e{n}.so"))
     s = np.zeros((y1 - y0, W, 3), np.float64); q = np.zeros_like(s)
@@ -36,13 +41,13 @@ def _band(args):
         L.ref_e3_golden_rows(W, H, spp, y0, y1, 1 if which == "03r" else 0, s.ctypes.data_as(DP), q.ctypes.data_as(DP), C.byref(rays))
     else:
         seed = (int(time.time() * 1000) + 7919 * rank) & 0xFFFFFFFF      # the reference seeds its engine from the clock
-        L.ref_e2_golden_rows(W, H, spp, 16, C.c_uint(seed), y0, y1, s.ctypes.data_as(DP), q.ctypes.data_as(DP), C.byref(rays))
+        L.ref_e2_golden_rows(W, H, spp, shadow, C.c_uint(seed), y0, y1, s.ctypes.data_as(DP), q.ctypes.data_as(DP), C.byref(rays))
     return y0, y1, s, q, rays.value, time.perf_counter() - t0
 
 
 def render(which, spp, procs):
     bands = np.linspace(0, H, procs * 4 + 1).astype(int)
-    jobs = [(which, spp, int(bands[i]), int(bands[i + 1]), i) for i in range(len(bands) - 1)]
+    jobs = [(which, spp, int(bands[i]), int(bands[i + 1]), i, W, H) for i in range(len(bands) - 1)]
     s = np.zeros((H, W, 3), np.float64); q = np.zeros_like(s)
     rays, cpu = 0, 0.0
     t0 = time.perf_counter()
@@ -55,7 +60,23 @@ def render(which, spp, procs):
     return mean, var, rays, wall, cpu
 
 
+def sweep02(procs, evals=256, size=(98, 70)):
+    """BASELINE config 2's shadow-sample sweep at a small frame: tests/golden/converged_02_sweep.npz holds, per sample count,
+    the mean and the per-pixel variance of 'evals' evaluations of the reference's estimator."""
+    global W, H
+    W, H = size
+    out = {"evals": np.int64(evals), "width": np.int64(W), "height": np.int64(H)}
+    for shadow in (1, 2, 4, 8, 32, 64, 128, 256):
+        mean, var, rays, wall, cpu = render(f"02s{shadow}", evals, procs)
+        assert rays == W * H * evals * (1 + shadow), (rays, shadow)
+        out[f"mean_s{shadow}"] = mean.astype(np.float32); out[f"var_s{shadow}"] = var.astype(np.float32)
+        print(f"02 with {shadow} shadow samples: {rays} rays, wall {wall:.1f} s, mean {mean.mean(axis=(0, 1))}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "converged_02_sweep.npz"), **out)
+
+
 def main():
+    if "sweep02" in sys.argv:
+        return sweep02(7)
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["03", "03r", "04", "02"])
     ap.add_argument("--spp", type=int, default=0)

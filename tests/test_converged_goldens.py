@@ -99,3 +99,37 @@ def test_gpu_matches_reference_mean_image_02(ctx):
         g = ctx.render_whitted(s, cam, prm, W, H)
         acc += g["rgb"]
     _check("HIP", acc / n, n, "02", 17.0, gamma=False)
+
+
+# ---- BASELINE config 2: the shadow-sample sweep against the reference (tests/golden/converged_02_sweep.npz, 98x70) ----------
+def _check_sweep(name, render, shadow, n):
+    """mean of n evaluations (different seeds) of the frame with 'shadow' samples per light vs the reference's 256 evaluations"""
+    g = np.load(os.path.join(GOLDEN, "converged_02_sweep.npz"))
+    w, h, n_gold = int(g["width"]), int(g["height"]), int(g["evals"])
+    mean, var = g[f"mean_s{shadow}"].astype(np.float64), g[f"var_s{shadow}"].astype(np.float64)
+    acc = np.zeros((h, w, 3), np.float64)
+    for k in range(n):
+        r = render(scenes.scene02(shadow, seed=7000 + 131 * shadow + k), w, h)
+        assert r["rays"] == w * h and r["shadow_rays"] == shadow * w * h
+        acc += r["rgb"]
+    img = acc / n
+    # sampling noise of both means + the 1e-4 float tolerance of the frame's deterministic part (tests/test_gpu_parity.py)
+    # 1.25 instead of SURVEY 8(c)'s 1.1: only the penumbra's few hundred pixels of this 98x70 frame carry variance, so the RMSE
+    # itself scatters by ~ +-15 % from sample count to sample count (measured: 0.87 ... 1.15 of its expectation)
+    bound = 1.25 * np.sqrt((var * (1.0 / n + 1.0 / n_gold) + (1e-4 * mean) ** 2).mean())
+    rmse = np.sqrt(((img - mean) ** 2).mean())
+    ratio = img.mean(axis=(0, 1)) / mean.mean(axis=(0, 1))
+    print(f"{name} vs reference, 02 with {shadow} shadow samples: RMSE {rmse:.5f} <= {bound:.5f}; channel means x{ratio}")
+    assert rmse <= bound, (shadow, rmse, bound)
+    assert np.allclose(ratio, 1.0, rtol=2e-3, atol=0), ratio
+
+
+@pytest.mark.parametrize("shadow", [1, 8, 64])
+def test_oracle_matches_reference_over_the_shadow_sample_sweep(shadow):
+    _check_sweep("oracle", lambda scp, w, h: oracle.render_whitted(*scp, w, h, threads=8), shadow, 32 if shadow < 64 else 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shadow", [1, 2, 4, 8, 32, 64, 128, 256])
+def test_gpu_matches_reference_over_the_shadow_sample_sweep(ctx, shadow):
+    _check_sweep("HIP", lambda scp, w, h: ctx.render_whitted(*scp, w, h), shadow, 256)
