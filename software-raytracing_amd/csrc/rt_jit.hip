@@ -312,7 +312,11 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     else {
         // same code generation as the Makefile's: contraction on (rt_strict.h turns it off for itself), '/' and sqrtf correctly rounded
         const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt"};
-        hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+        std::vector<const char*> ov(opts, opts + sizeof opts / sizeof opts[0]);
+        std::vector<std::string> extra;      // RT_MI355_JIT_FLAGS="-mllvm;-amdgpu-sched-strategy=max-ilp": extra compiler options (experiments; ';'-separated)
+        if (const char* xf = getenv("RT_MI355_JIT_FLAGS")) { std::string cur; for (const char* q = xf;; ++q) { if (*q == ';' || *q == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*q) break; } else cur += *q; } }
+        for (const std::string& x : extra) ov.push_back(x.c_str());
+        hiprtcResult r = hiprtcCompileProgram(prog, (int)ov.size(), ov.data());
         if (r != HIPRTC_SUCCESS) {
             size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
             std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
