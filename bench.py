@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a run that is still going prints every thread's stack and exits (0 = off): a rank stuck in a collective must not hang the job")
     args = ap.parse_args()
 
+    # the image's own compiler library in place of the older one PyTorch bundles (rtamd/lib.py; +3 % on the generated kernel)
+    from rtamd import lib as _lib_early
+    jit_compiler = _lib_early.prefer_system_compiler()
     import torch
     import torch.distributed as dist
     from rtamd import abi, lib, scenes, shard
@@ -216,7 +219,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"04_PathTracingLights scene (5 planes, 3 spheres, 1 emissive rectangle), {W}x{H}, {SPP} spp, max depth 6, seed 1",
-                       "samples_per_step": W * H * SPP, "rays_per_step": rays_step, "samples_per_sec": W * H * SPP * args.steps / dt,
+                       "jit_compiler": jit_compiler, "samples_per_step": W * H * SPP, "rays_per_step": rays_step, "samples_per_sec": W * H * SPP * args.steps / dt,
                        "parallelism": (f"sample-range x{world}, one all-reduce(sum) of the {W * H * 16 / 1e6:.1f} MB accumulator" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")) if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": traffic, "traffic_source": ("profiles/r02_pmc_hbm_traffic.json: separate rocprofv3 --pmc passes of this command, not this run; 8 partial images (sample slices, DESIGN.md 5) on purpose: algorithmic bytes are 16 B/pixel = 132.7 MB" if traffic is not None else None), "kernel": {2: "k_path_jit (scene-specialised rt::path_body<4, true>, hiprtc; kernel_ms includes k_sum_slices, 0.2 ms)", 1: "rt::k_path<4, true>", 0: "rt::k_path_tiled<4>"}.get(ctx.last_path_kernel()[0], "?"), "kernel_ms": k_ms, "kernel_ms_steps": [round(x, 3) for x in kernel_ms], "flops_per_ray": fpr, "rays_per_launch": rays,

@@ -2,6 +2,7 @@
 no CPU fallback: a missing library or a missing gfx950 device raises."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -16,6 +17,24 @@ class RtError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"rt_mi355 error {code}: {msg}")
         self.code = code
+
+
+SYSTEM_COMGR = "/opt/rocm/lib/libamd_comgr.so.3"
+
+
+def prefer_system_compiler():
+    """Call BEFORE `import torch`.  The scene-specialised kernels are compiled at run time through hiprtc -> libamd_comgr of
+    whichever ROCm runtime the process loaded first; PyTorch bundles an older one (ROCm 7.0) than the image ships (7.2), and the
+    older compiler's kernel is 3 % slower (tools/runtime_probe.py).  Loading the system's compiler library first, with global
+    visibility, makes it the provider of amd_comgr_* for the whole process (same soname, same ABI).  A host that never imports
+    torch gets the system compiler anyway.  -> a description of the compiler in use."""
+    if os.environ.get("RT_MI355_SYSTEM_COMGR", "1") != "0" and "torch" not in sys.modules:
+        try:
+            C.CDLL(SYSTEM_COMGR, mode=C.RTLD_GLOBAL)
+            return SYSTEM_COMGR + " (loaded before torch)"
+        except OSError:
+            pass
+    return "the ROCm runtime bundled with PyTorch" if "torch" in sys.modules else "the first ROCm runtime the process loads"
 
 
 def load():

@@ -10,6 +10,12 @@ sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))     # orc.py: the checker's binding
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Before anything imports torch: the tests run the scene-specialised kernels as the benchmark runs them, compiled by the image's
+# own compiler library rather than the older one PyTorch bundles (rtamd/lib.py prefer_system_compiler; the C++ example binaries,
+# which several tests compare with, use the system runtime anyway).  RT_MI355_SYSTEM_COMGR=0 keeps PyTorch's.
+from rtamd import lib as _lib_early  # noqa: E402
+JIT_COMPILER = _lib_early.prefer_system_compiler()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
