@@ -134,3 +134,15 @@ def test_device_group_partition_covers_every_sample_once():
                 cur = e.value; sizes.append(e.value - b.value)
             assert cur == s1 and max(sizes) - min(sizes) <= 1
     assert L.rt_debug_group_share(0, 4, 2, 2, C.byref(b), C.byref(e)) == abi.RT_ERR_BAD_ARG
+
+
+def test_prefer_system_compiler_is_safe_to_call_any_time():
+    """rtamd.lib.prefer_system_compiler(): conftest.py has called it before anything imported torch (JIT_COMPILER says which
+    compiler library serves the process); calling it again, or after torch is in, must neither raise nor load anything new."""
+    import conftest
+    from rtamd import lib as L
+    assert isinstance(conftest.JIT_COMPILER, str) and conftest.JIT_COMPILER
+    if os.path.exists(L.SYSTEM_COMGR) and os.environ.get("RT_MI355_SYSTEM_COMGR", "1") != "0":
+        assert L.SYSTEM_COMGR in conftest.JIT_COMPILER
+    import torch  # noqa: F401
+    assert "PyTorch" in L.prefer_system_compiler()
