@@ -64,7 +64,8 @@ struct HostScene {
     Bvh bvh;
     // Appends one slot of n float4 already pushed to 'slots' to the run/chunk tables: runs never straddle a chunk, so a
     // scene too large for LDS can be walked chunk by chunk (k_path_tiled).
-    void add_slot(int dtype, size_t n_f4, int prim, const float* tri = nullptr) {
+    // pts/n_pts: world-space corners (triangles; strict rectangles, whose slot holds the object frame instead of plane rows)
+    void add_slot(int dtype, size_t n_f4, int prim, const float* pts = nullptr, int n_pts = 3) {
         const int bytes = (int)(n_f4 * 16);
         const int start = (int)(slots.size() * 16) - bytes;
         {
@@ -83,8 +84,9 @@ struct HostScene {
                     const float p[3] = {G1.x * u + G2.x * v + G.x * G.w, G1.y * u + G2.y * v + G.y * G.w, G1.z * u + G2.z * v + G.z * G.w};
                     for (int a = 0; a < 3; ++a) { it.lo[a] = std::min(it.lo[a], p[a]); it.hi[a] = std::max(it.hi[a], p[a]); }
                 }
-            } else if (dtype == PRIM_TRI && tri) {
-                for (int a = 0; a < 3; ++a) { it.lo[a] = std::min(tri[a], std::min(tri[3 + a], tri[6 + a])); it.hi[a] = std::max(tri[a], std::max(tri[3 + a], tri[6 + a])); }
+            } else if ((dtype == PRIM_TRI || dtype == PRIM_TRI_STRICT || dtype == PRIM_RECT_STRICT) && pts) {
+                for (int a = 0; a < 3; ++a) { it.lo[a] = INFINITY; it.hi[a] = -INFINITY; }
+                for (int k = 0; k < n_pts; ++k) for (int a = 0; a < 3; ++a) { it.lo[a] = std::min(it.lo[a], pts[3 * k + a]); it.hi[a] = std::max(it.hi[a], pts[3 * k + a]); }
             } else it.bounded = false;       // planes
             if (n_f4 == 8) {
                 // wide slots carry a bounding sphere (centre, R^2) in their last float4: k_path_tiled skips a rectangle / triangle
@@ -200,6 +202,123 @@ TriBasis tri_basis(const float* f) {
     return T;
 }
 
+// ---- coplanar planar elements of different arithmetic (rt_device.h PRIM_*_STRICT) ----------------------------------------------
+// Every planar element of a path scene (plane, rectangle, each of a box's six faces, triangle) as its supporting plane in
+// double precision plus its outline; two of them that lie in one plane (normal within 1e-5, offset within 1e-5 of the scene's
+// scale), overlap in more than a line and are NOT evaluated by identical arithmetic in the reference (same class and the same
+// numbers feeding t) are flagged: their slots take the reference's own operation sequence.  flags[prim * 6 + face].
+struct BoxFace { int ax; float off; int u; float ulo, uhi; int v; float vlo, vhi; float sgn; };
+void box_faces(float hw, float hh, float hl, BoxFace out[6]) {
+    // scene::Box::intersectsRay (04 Scene/Box.hpp:84-131): the face order of its six tests; the two Z faces take y up to +halfLength as written (:88, :95)
+    const BoxFace f[6] = {{2, -hl, 0, -hw, hw, 1, -hh, hl, -1.0f}, {2, hl, 0, -hw, hw, 1, -hh, hl, 1.0f},
+                          {0, -hw, 1, -hh, hh, 2, -hl, hl, -1.0f}, {0, hw, 1, -hh, hh, 2, -hl, hl, 1.0f},
+                          {1, -hh, 0, -hw, hw, 2, -hl, hl, -1.0f}, {1, hh, 0, -hw, hw, 2, -hl, hl, 1.0f}};
+    for (int k = 0; k < 6; ++k) out[k] = f[k];
+}
+// world corners of the rectangle 'coordinate ax = off, u in [ulo, uhi], v in [vlo, vhi]' of the frame with rows ri at pos
+void frame_rect_corners(const float ri[9], const float pos[3], int ax, float off, int u, float ulo, float uhi, int v, float vlo, float vhi, float out[12]) {
+    const float us[4] = {ulo, uhi, uhi, ulo}, vs[4] = {vlo, vlo, vhi, vhi};
+    for (int k = 0; k < 4; ++k) for (int a = 0; a < 3; ++a) out[3 * k + a] = pos[a] + off * ri[3 * ax + a] + us[k] * ri[3 * u + a] + vs[k] * ri[3 * v + a];
+}
+struct Planar {
+    int prim, face, cls;            // cls: 0 plane, 1 rectangle / box face, 2 triangle
+    double N[3], W;                 // canonical unit normal (first significant component positive), N.p = W
+    double P[4][3]; int np;         // outline (np = 0: unbounded)
+    float same[8]; int n_same;      // the numbers that feed t in the reference: equal class + equal numbers = identical arithmetic, a true tie there too
+};
+bool convex_overlap(const Planar& a, const Planar& b) {
+    if (a.np == 0 || b.np == 0) return true;
+    double scale = 0.0;
+    for (int k = 0; k < a.np; ++k) for (int c = 0; c < 3; ++c) scale = std::max(scale, std::fabs(a.P[k][c] - a.P[0][c]));
+    const Planar* pp[2] = {&a, &b};
+    for (int w = 0; w < 2; ++w) {   // separating axes: the in-plane edge normals of both outlines
+        const Planar& e = *pp[w];
+        for (int k = 0; k < e.np; ++k) {
+            const double* p0 = e.P[k]; const double* p1 = e.P[(k + 1) % e.np];
+            const double ed[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+            double ax[3] = {ed[1] * a.N[2] - ed[2] * a.N[1], ed[2] * a.N[0] - ed[0] * a.N[2], ed[0] * a.N[1] - ed[1] * a.N[0]};
+            const double l = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            if (!(l > 0.0)) continue;
+            for (double& v : ax) v /= l;
+            double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+            for (int q = 0; q < 2; ++q) for (int j = 0; j < pp[q]->np; ++j) {
+                const double* P = pp[q]->P[j]; const double x = P[0] * ax[0] + P[1] * ax[1] + P[2] * ax[2];
+                lo[q] = std::min(lo[q], x); hi[q] = std::max(hi[q], x);
+            }
+            if (std::min(hi[0], hi[1]) - std::max(lo[0], lo[1]) <= 1e-7 * std::max(scale, 1e-3)) return false;      // apart, or touching along a line only
+        }
+    }
+    return true;
+}
+std::vector<unsigned char> find_coplanar(const rt_scene* s) {
+    std::vector<unsigned char> flags((size_t)s->n_prims * 6, 0);
+    std::vector<Planar> items;
+    auto finish = [&](Planar& q, const double n_in[3], const double p[3]) {
+        double n[3] = {n_in[0], n_in[1], n_in[2]};
+        const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (!(l > 0.0) || !std::isfinite(l)) return;
+        for (double& v : n) v /= l;
+        double sgn = 1.0;
+        for (int a = 0; a < 3; ++a) if (std::fabs(n[a]) > 1e-6) { sgn = n[a] < 0.0 ? -1.0 : 1.0; break; }
+        for (int a = 0; a < 3; ++a) q.N[a] = sgn * n[a];
+        q.W = q.N[0] * p[0] + q.N[1] * p[1] + q.N[2] * p[2];
+        if (std::isfinite(q.W)) items.push_back(q);
+    };
+    for (int i = 0; i < s->n_prims; ++i) {
+        const rt_prim& P = s->prims[i];
+        const float* f = P.f;
+        if (P.type == RT_PRIM_PLANE) {
+            Planar q{}; q.prim = i; q.face = 0; q.cls = 0; q.np = 0; q.n_same = 6;
+            for (int a = 0; a < 6; ++a) q.same[a] = f[a];
+            const double n[3] = {f[3], f[4], f[5]}, p[3] = {f[0], f[1], f[2]};
+            finish(q, n, p);
+        } else if (P.type == RT_PRIM_TRIANGLE) {
+            const TriBasis T = tri_basis(f);
+            if (T.degenerate) continue;
+            Planar q{}; q.prim = i; q.face = 0; q.cls = 2; q.np = 3; q.n_same = 6;
+            for (int a = 0; a < 3; ++a) { q.same[a] = f[a]; q.same[3 + a] = T.n[a]; }
+            for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) q.P[k][a] = f[3 * k + a];
+            const double n[3] = {T.n[0], T.n[1], T.n[2]}, p[3] = {f[0], f[1], f[2]};
+            finish(q, n, p);
+        } else if (P.type == RT_PRIM_RECT || P.type == RT_PRIM_BOX) {
+            const bool box = P.type == RT_PRIM_BOX;
+            const float* orient = box ? f + 6 : f + 5;
+            float neg[3] = {-orient[0], -orient[1], -orient[2]}, ri[9];
+            rotation_mat(neg, ri);
+            BoxFace F[6]; int nf = 1;
+            if (box) { box_faces(f[3] / 2.0f, f[4] / 2.0f, f[5] / 2.0f, F); nf = 6; }
+            else F[0] = BoxFace{2, 0.0f, 0, -f[3] / 2.0f, f[3] / 2.0f, 1, -f[4] / 2.0f, f[4] / 2.0f, 1.0f};
+            for (int k = 0; k < nf; ++k) {
+                Planar q{}; q.prim = i; q.face = k; q.cls = 1; q.np = 4; q.n_same = 8;
+                for (int a = 0; a < 3; ++a) { q.same[a] = f[a]; q.same[3 + a] = orient[a]; }
+                q.same[6] = (float)F[k].ax; q.same[7] = F[k].off;
+                float c[12]; frame_rect_corners(ri, f, F[k].ax, F[k].off, F[k].u, F[k].ulo, F[k].uhi, F[k].v, F[k].vlo, F[k].vhi, c);
+                for (int j = 0; j < 4; ++j) for (int a = 0; a < 3; ++a) q.P[j][a] = c[3 * j + a];
+                const double n[3] = {ri[3 * F[k].ax], ri[3 * F[k].ax + 1], ri[3 * F[k].ax + 2]}, p[3] = {c[0], c[1], c[2]};
+                finish(q, n, p);
+            }
+        }
+    }
+    if (items.size() < 2) return flags;
+    std::vector<int> order(items.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return items[a].W < items[b].W; });
+    long long budget = 4000000;      // pair checks: a scene of thousands of coplanar elements (a tessellated floor) is cut off, not quadratic
+    for (size_t x = 0; x < order.size() && budget > 0; ++x) {
+        const Planar& a = items[order[x]];
+        const double tol = 1e-5 * std::max(1.0, std::fabs(a.W));
+        for (size_t y = x + 1; y < order.size() && items[order[y]].W - a.W <= tol && budget > 0; ++y, --budget) {
+            const Planar& b = items[order[y]];
+            if (a.prim == b.prim) continue;
+            if (std::fabs(a.N[0] - b.N[0]) > 1e-5 || std::fabs(a.N[1] - b.N[1]) > 1e-5 || std::fabs(a.N[2] - b.N[2]) > 1e-5) continue;
+            if (a.cls == b.cls && a.n_same == b.n_same && !memcmp(a.same, b.same, sizeof(float) * (size_t)a.n_same)) continue;   // identical arithmetic: a tie in the reference as well
+            if (!convex_overlap(a, b)) continue;
+            flags[(size_t)a.prim * 6 + a.face] = 1; flags[(size_t)b.prim * 6 + b.face] = 1;
+        }
+    }
+    return flags;
+}
+
 // Validates rt_scene and builds the device layout documented in rt_device.h.
 // tmin: the path render's tMin (spheres of radius > RT_BIG_SPHERE_RATIO * tmin get the refined root, rt_device.h); unused for Whitted scenes
 int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/, float tmin, HostScene& H) {
@@ -237,6 +356,14 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         int type = variant == 0 ? MAT_PHONG : MAT_NONE;
         H.mats.push_back(f4(1, 1, 1, __builtin_bit_cast(float, type))); H.mats.push_back(f4(0.0f, 16.0f, 1.0f, 1.0f)); H.mats.push_back(f4(1.0f, 0, 1.0f, 0));
     }
+    // path scenes: planar elements coplanar with an element of other arithmetic take the reference's operation sequence
+    // (rt_device.h PRIM_*_STRICT); RT_MI355_STRICT_COPLANAR=0 keeps the fast forms (A/B switch of the parity tests)
+    std::vector<unsigned char> strict_flags;
+    {
+        const char* e = getenv("RT_MI355_STRICT_COPLANAR");
+        if (variant != 0 && !(e && e[0] == '0')) strict_flags = find_coplanar(s);
+    }
+    auto strict_at = [&](int prim, int face) { return !strict_flags.empty() && strict_flags[(size_t)prim * 6 + face] != 0; };
     for (int i = 0; i < s->n_prims; ++i) {
         const rt_prim& P = s->prims[i];
         if (P.material >= s->n_materials) return fail(c, RT_ERR_BAD_ARG, "prim " + std::to_string(i) + ": material index out of range");
@@ -250,6 +377,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
         {   // slot layout (rt_device.h): every query of the path scenes; the shadow samples of 02
             float4 G = f4(0, 0, 0, 0), A = f4(0, 0, 0, 0), B = f4(0, 0, 0, 0), C = f4(0, 0, 0, 0), G1 = G, G2 = G, G3 = G;
             bool wide = false;
+            float strict_pts[12]; int n_strict_pts = 0;      // a strict rectangle's corners (its slot no longer holds plane rows to bound it by)
             switch (P.type) {
             case RT_PRIM_SPHERE: {
                 if (variant != 0 && fabsf(f[3]) > RT_BIG_SPHERE_RATIO * tmin) dtype = PRIM_SPHERE_BIG;
@@ -260,7 +388,8 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
                 int axis = -1;    // unit normal exactly +-e_axis: shares 1/d per ray (bit-identical to the general form)
                 for (int a = 0; a < 3; ++a)
                     if (fabsf(f[3 + a]) == 1.0f && f[3 + (a + 1) % 3] == 0.0f && f[3 + (a + 2) % 3] == 0.0f) axis = a;
-                if (axis >= 0) { G = f4(f[axis], 0, 0, 0); dtype = PRIM_AAPLANE_X + axis; H.has_aa = 1; }
+                if (strict_at(i, 0)) { G = f4(f[3], f[4], f[5], 0); A = f4(f[0], f[1], f[2], 0); dtype = PRIM_PLANE_STRICT; }   // n, p0 (k = 0: A.xyz is free)
+                else if (axis >= 0) { G = f4(f[axis], 0, 0, 0); dtype = PRIM_AAPLANE_X + axis; H.has_aa = 1; }
                 else G = f4(f[3], f[4], f[5], f[3] * f[0] + f[4] * f[1] + f[5] * f[2]);
                 B = f4(f[3], f[4], f[5], 0); C = B;
                 break; }
@@ -272,6 +401,13 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
                 G1 = f4(ri[0], ri[1], ri[2], -dotc(0)); G2 = f4(ri[3], ri[4], ri[5], -dotc(1)); G3 = f4(f[3] / 2.0f, f[4] / 2.0f, 0, 0);
                 B = f4(rf[2], rf[5], rf[8], 0); C = f4(ri[6], ri[7], ri[8], 0);
                 wide = true;
+                if (strict_at(i, 0)) {      // object frame instead of plane rows: strict_rect (rt_device.h)
+                    const float hw = f[3] / 2.0f, hh = f[4] / 2.0f;                                     // Rectangle.hpp:66-67
+                    G = f4(ri[0], ri[1], ri[2], 0.0f); A = f4(f[0], f[1], f[2], 0); G1 = f4(ri[3], ri[4], ri[5], -hw); G2 = f4(ri[6], ri[7], ri[8], -hh);
+                    G3 = f4(hw, hh, __builtin_bit_cast(float, 2), 0);
+                    frame_rect_corners(ri, f, 2, 0.0f, 0, -hw, hw, 1, -hh, hh, strict_pts); n_strict_pts = 4;
+                    dtype = PRIM_RECT_STRICT;
+                }
                 break; }
             case RT_PRIM_TRIANGLE: {
                 const TriBasis T = tri_basis(f);
@@ -282,6 +418,10 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
                 if (T.degenerate) G1 = f4(0, 0, 0, -1.0f);
                 B = f4(n[0], n[1], n[2], 0); C = B;
                 wide = true;
+                if (strict_at(i, 0) && !T.degenerate) {      // strict_tri (rt_device.h)
+                    G = f4(n[0], n[1], n[2], 0); A = f4(f[0], f[1], f[2], 0); G1 = f4(r0[0], r0[1], r0[2], 0); G2 = f4(r1[0], r1[1], r1[2], 0);
+                    dtype = PRIM_TRI_STRICT;
+                }
                 break; }
             case RT_PRIM_BOX: {
                 // scene::Box (04 Scene/Box.hpp:55-158) tests its six faces in a fixed order against a shrinking tMax - exactly
@@ -294,13 +434,25 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
                 auto dotc = [&](int row) { return ri[3 * row] * f[0] + ri[3 * row + 1] * f[1] + ri[3 * row + 2] * f[2]; };
                 const float flip = (P.flags & RT_PRIM_FLAG_FLIP_NORMALS) ? -1.0f : 1.0f;
                 // face: plane axis, its offset, the two in-plane axes with their [lo, hi] ranges, local normal sign
-                struct Face { int ax; float off; int u; float ulo, uhi; int v; float vlo, vhi; float sgn; };
-                const Face faces[6] = {
-                    {2, -hl, 0, -hw, hw, 1, -hh, hl, -1.0f}, {2, hl, 0, -hw, hw, 1, -hh, hl, 1.0f},      // y up to +halfLength: as written (:88, :95)
-                    {0, -hw, 1, -hh, hh, 2, -hl, hl, -1.0f}, {0, hw, 1, -hh, hh, 2, -hl, hl, 1.0f},
-                    {1, -hh, 0, -hw, hw, 2, -hl, hl, -1.0f}, {1, hh, 0, -hw, hw, 2, -hl, hl, 1.0f}};
-                for (const Face& F : faces) {
+                BoxFace faces[6];
+                box_faces(hw, hh, hl, faces);
+                for (int fk = 0; fk < 6; ++fk) {
+                    const BoxFace& F = faces[fk];
                     const float s = F.sgn * flip;
+                    if (strict_at(i, fk)) {      // this face in the reference's operation sequence: strict_rect (rt_device.h)
+                        H.slots.push_back(f4(ri[0], ri[1], ri[2], F.off));                                                // G: row 0, the face's coordinate
+                        H.slots.push_back(f4(f[0], f[1], f[2], 0));                                                       // A: pos, k = 0
+                        H.slot_mat_fixups.push_back(H.slots.size());
+                        H.slots.push_back(f4(s * rf[F.ax], s * rf[3 + F.ax], s * rf[6 + F.ax], __builtin_bit_cast(float, mat)));
+                        H.slots.push_back(f4(s * ri[3 * F.ax], s * ri[3 * F.ax + 1], s * ri[3 * F.ax + 2], 0));
+                        H.slots.push_back(f4(ri[3], ri[4], ri[5], F.ulo));                                                // G1: row 1, u range from
+                        H.slots.push_back(f4(ri[6], ri[7], ri[8], F.vlo));                                                // G2: row 2, v range from
+                        H.slots.push_back(f4(F.uhi, F.vhi, __builtin_bit_cast(float, F.ax), 0));                          // G3
+                        H.slots.push_back(f4(0, 0, 0, 0));
+                        float pts[12]; frame_rect_corners(ri, f, F.ax, F.off, F.u, F.ulo, F.uhi, F.v, F.vlo, F.vhi, pts);
+                        H.add_slot(PRIM_RECT_STRICT, 8, i, pts, 4);
+                        continue;
+                    }
                     const float umid = 0.5f * (F.ulo + F.uhi), vmid = 0.5f * (F.vlo + F.vhi);   // asymmetric ranges: |u - mid| <= half
                     H.slots.push_back(f4(ri[3 * F.ax], ri[3 * F.ax + 1], ri[3 * F.ax + 2], dotc(F.ax) + F.off));          // G
                     H.slots.push_back(f4(0, 0, 0, 0));                                                                   // A
@@ -321,7 +473,8 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
             H.slots.push_back(G); H.slots.push_back(A); H.slot_mat_fixups.push_back(H.slots.size()); H.slots.push_back(B); H.slots.push_back(C);
             if (wide) { H.slots.push_back(G1); H.slots.push_back(G2); H.slots.push_back(G3); H.slots.push_back(f4(0, 0, 0, 0)); }
             // rectangles and triangles share one loop in the kernel but not one run: the run type picks the inside test
-            H.add_slot(dtype, wide ? 8 : 4, i, P.type == RT_PRIM_TRIANGLE ? f : nullptr);
+            if (n_strict_pts) H.add_slot(dtype, 8, i, strict_pts, n_strict_pts);
+            else H.add_slot(dtype, wide ? 8 : 4, i, P.type == RT_PRIM_TRIANGLE ? f : nullptr);
             if (variant != 0) { H.info.push_back(make_int4(dtype, 0, mat, (int)P.flags)); continue; }
             dtype = P.type;
         }
@@ -404,7 +557,7 @@ int fill_and_upload_scene(rt_ctx* c, const HostScene& H, const BlobLayout& L, hi
     D.whitted_branches = H.whitted_branches;
     D.srun_pack[0] = D.srun_pack[1] = 0ULL; D.srun_packed = H.sruns.size() <= 8;
     for (size_t r = 0; r < H.sruns.size() && r < 8; ++r) {
-        if (H.sruns[r].z > 8191) D.srun_packed = 0;
+        if (H.sruns[r].z > 8191 || H.sruns[r].x > 7) D.srun_packed = 0;      // 3 bits of type, 13 of count
         D.srun_pack[r / 4] |= (unsigned long long)(((uint32_t)H.sruns[r].x | ((uint32_t)H.sruns[r].z << 3)) & 0xFFFFU) << ((r % 4) * 16);
     }
     D.off_sruns = (int)(o_sruns / 16); D.n_sruns = (int)H.sruns.size(); D.slot_bytes = (int)(H.slots.size() * 16);
@@ -1106,6 +1259,18 @@ int32_t rt_debug_bvh_probe(const rt_scene* scene, int32_t variant, int32_t* out)
     if ((int)B.refs.size() != n_bounded || B.unbounded.size() + B.refs.size() != H.items.size()) ++bad;
     if (out) { out[0] = n_nodes; out[1] = (int)B.refs.size(); out[2] = (int)B.unbounded.size(); out[3] = B.depth; out[4] = (int)H.items.size(); }
     return bad;
+}
+// rt_debug_strict_slots: compiles a path scene on the host (no GPU needed) and counts the slots that take the reference's own
+// operation sequence because they are coplanar with an element of other arithmetic (rt_device.h PRIM_*_STRICT).
+// out[0..2] = {strict planes, strict rectangles / box faces, strict triangles}.  Returns their total, or an error code < 0.
+int32_t rt_debug_strict_slots(const rt_scene* scene, int32_t variant, int32_t* out) {
+    HostScene H;
+    int rc = compile_scene(nullptr, scene, variant, variant == 3 ? 0.001f : 0.01f, H);
+    if (rc) return rc;
+    int n[3] = {0, 0, 0};
+    for (const int4& r : H.sruns) if (is_strict_type(r.x)) n[r.x - PRIM_PLANE_STRICT] += r.z;
+    if (out) { out[0] = n[0]; out[1] = n[1]; out[2] = n[2]; }
+    return n[0] + n[1] + n[2];
 }
 // the device group's partition of a sample range (rt_create_multi); needs no GPU
 int32_t rt_debug_group_share(int32_t s0, int32_t s1, int32_t i, int32_t n, int32_t* b, int32_t* e) {

@@ -23,7 +23,7 @@ __device__ __forceinline__ void bvh_take(BvhHit& H, bool ok, float t, uint32_t q
 // One slot against the ray; ref = blob byte offset of the slot | device type.
 __device__ __forceinline__ void bvh_test(const SceneMem<false> M, uint32_t ref, f3 o, f3 d, f3 inv_d, float tmin, float tminp, BvhHit& H) {
     const uint32_t q = ref & ~63U;
-    const int type = (int)(ref & 7U);
+    const int type = (int)(ref & 15U);
     if (is_sphere_type(type)) {
         float4 g = M.ld4(q);
         f3 co = F3(g) - o;
@@ -46,6 +46,10 @@ __device__ __forceinline__ void bvh_test(const SceneMem<false> M, uint32_t ref, 
         float4 g = M.ld4(q);
         float t = (g.w - dot(F3(g), o)) * rcp_fast(dot(F3(g), d));
         bvh_take(H, t >= tminp, t, q);
+    } else if (is_strict_type(type)) {      // the reference's own operation sequence (rt_device.h PRIM_*_STRICT): same bits as closest_hit_runs
+        float t;
+        const bool ok = strict_slot<false>(M, type, q, o, strict_dir(d), tminp, t);
+        bvh_take(H, ok, t, q);
     } else {
         float4 g = M.ld4(q), g1 = M.ld4(q + SLOT_G1), g2 = M.ld4(q + SLOT_G2);
         float t = (g.w - dot(F3(g), o)) * rcp_fast(dot(F3(g), d));

@@ -56,7 +56,16 @@ __device__ __forceinline__ Scn scn_over(const DevScene& S, const float4* base) {
     return v;
 }
 
-enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLANE_X = 4, PRIM_AAPLANE_Y = 5, PRIM_AAPLANE_Z = 6, PRIM_SPHERE_BIG = 7 };
+enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLANE_X = 4, PRIM_AAPLANE_Y = 5, PRIM_AAPLANE_Z = 6, PRIM_SPHERE_BIG = 7,
+       PRIM_PLANE_STRICT = 8, PRIM_RECT_STRICT = 9, PRIM_TRI_STRICT = 10 };
+// PRIM_*_STRICT: a planar slot whose supporting plane coincides with that of ANOTHER slot the reference evaluates with different
+// arithmetic (a box face resting on a plane, a rectangle lying in a triangle's plane, ...; found when the scene is compiled,
+// rt_api.hip find_coplanar).  In exact arithmetic the two distances are equal; in the reference the rounding of two different
+// formulas decides which element a ray sees (04 Scene/Rectangle.hpp:58-70 works in the object frame, Scene/Plane.hpp in the world
+// frame), about half of the time against scene order.  The fast slot forms fold the object frame into the plane equation and
+// produce an EXACT tie there, which scene order always decides - a different image (a glass box on a floor plane: mean -1.1 %,
+// profiles/r02_bias_scan.txt).  Such slots are therefore tested in the reference's own operation sequence (strict_* below: its
+// operator order, no contraction, true division and square root), so the same rounding decides.  No reference scene has one.
 // PRIM_SPHERE_BIG: a sphere whose radius exceeds RT_BIG_SPHERE_RATIO x tMin (03's ground sphere: r = 100, tMin = 0.001).  Same
 // slot, same test, but the square root of the discriminant is refined (sqrt_refined below).  Why: the hardware square root is
 // good to 1 ulp but not unbiased (v_sqrt_f32: 14.9 % of results one ulp LOW, 0.01 % high, mean -0.149 ulp; the refined form:
@@ -70,6 +79,8 @@ enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLAN
 #define RT_BIG_SPHERE_RATIO 30000.0f
 __device__ __host__ inline bool is_sphere_type(int t) { return t == PRIM_SPHERE || t == PRIM_SPHERE_BIG; }
 __device__ __host__ inline bool is_aaplane_type(int t) { return t >= PRIM_AAPLANE_X && t <= PRIM_AAPLANE_Z; }
+__device__ __host__ inline bool is_strict_type(int t) { return t >= PRIM_PLANE_STRICT; }
+__device__ __host__ inline bool is_wide_type(int t) { return t == PRIM_RECT || t == PRIM_TRI || t == PRIM_RECT_STRICT || t == PRIM_TRI_STRICT; }   // 8 float4 per slot
 enum { MAT_PHONG = 0, MAT_DIFFUSE = 1, MAT_METAL = 2, MAT_DIELECTRIC = 3, MAT_LIGHT = 4, MAT_NONE = 5 };
 
 // ---- float3 -----------------------------------------------------------------------------------
@@ -185,6 +196,66 @@ template <bool LDS> struct SceneMem {
     }
 };
 
+// ---- planar slots in the reference's own operation sequence (PRIM_*_STRICT) ---------------------------------------------------
+// Each returns "the element's test passes for tMax = +inf" and its t; the caller adds t <= closest.  tminp = max(tMin, smallest
+// positive float) folds the reference's "t > 0 && t >= tMin".
+#pragma clang fp contract(off)
+// The reference's rays are normalised by Ray's constructor (Common/Ray.hpp:33-34, math::Normalize Math.hpp:233-238), so the length
+// of a direction is 1 to within an ulp THERE; the kernels' directions are unit by construction (reflect / refract / sampling frame),
+// to a few 1e-7 and not with the rounding pattern of a division by the length.  Where the last bit of t decides, the strict tests
+// therefore see the direction as the reference would hold it: d / |d| in its operation order.
+__device__ __forceinline__ f3 strict_dir(f3 d) {
+    const float len = sqrtf((d.x * d.x) + (d.y * d.y) + (d.z * d.z));
+    return len > 0.0f ? F3(d.x / len, d.y / len, d.z / len) : F3(0.0f, 0.0f, 0.0f);
+}
+// Ray::intersectsPlane (Common/Ray.hpp:223-249).  Slot: G = (n, -), A = (p0, 0).
+__device__ __forceinline__ bool strict_plane(f3 n, f3 p0, f3 o, f3 d, float tminp, float& t) {
+    const float dn = (d.x * n.x) + (d.y * n.y) + (d.z * n.z);
+    t = ((n.x * p0.x - n.x * o.x) + (n.y * p0.y - n.y * o.y) + (n.z * p0.z - n.z * o.z)) / dn;
+    return (dn != 0.0f) & (t >= tminp);
+}
+// scene::Rectangle::intersectsRay (04 Scene/Rectangle.hpp:58-70) and one face of scene::Box::intersectsRay (Scene/Box.hpp:62-131):
+// the ray goes to the object frame - origin R*(o - pos), direction Normalize(R*d) (Ray's constructor) with R = the three rows
+// r0, r1, r2 of GetRotationMat(-orientation) - and meets the axis-aligned rectangle 'coordinate ax = off' there
+// (Ray::intersectsAARectangleXy/Yz/Xz, Common/Ray.hpp:263-351): t = (off - o'[ax]) / d'[ax], then the two other coordinates at t
+// against [ulo, uhi] x [vlo, vhi] (u, v = the remaining axes in increasing order).
+// Slot: G = (r0, off), A = (pos, 0), G1 = (r1, ulo), G2 = (r2, vlo), G3 = (uhi, vhi, ax as int bits, -).
+__device__ __forceinline__ bool strict_rect(f3 r0, f3 r1, f3 r2, f3 pos, int ax, float off, float ulo, float uhi, float vlo, float vhi,
+                                            f3 o, f3 d, float tminp, float& t) {
+    const f3 om = F3(o.x - pos.x, o.y - pos.y, o.z - pos.z);
+    const f3 oo = F3(r0.x * om.x + r0.y * om.y + r0.z * om.z, r1.x * om.x + r1.y * om.y + r1.z * om.z, r2.x * om.x + r2.y * om.y + r2.z * om.z);
+    f3 dd = F3(r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z, r2.x * d.x + r2.y * d.y + r2.z * d.z);
+    const float len = sqrtf((dd.x * dd.x) + (dd.y * dd.y) + (dd.z * dd.z));      // math::Normalize (Math.hpp:233-238)
+    dd = len > 0.0f ? F3(dd.x / len, dd.y / len, dd.z / len) : F3(0.0f, 0.0f, 0.0f);
+    const float oa = ax == 0 ? oo.x : (ax == 1 ? oo.y : oo.z), da = ax == 0 ? dd.x : (ax == 1 ? dd.y : dd.z);
+    const float ou = ax == 0 ? oo.y : oo.x, du = ax == 0 ? dd.y : dd.x;
+    const float ov = ax == 2 ? oo.y : oo.z, dv = ax == 2 ? dd.y : dd.z;
+    t = (off - oa) / da;
+    const float u = ou + du * t, v = ov + dv * t;
+    return (t >= tminp) & (u >= ulo) & (u <= uhi) & (v >= vlo) & (v <= vhi);
+}
+// Ray::intersectsTriangle (Common/Ray.hpp:150-212) with the normal and rows 0, 1 of Inverse([e2 e1 n]) precomputed on the host by
+// the same float operations.  Slot: G = (n, -), A = (v0, 0), G1 = (row 0, -), G2 = (row 1, -).
+__device__ __forceinline__ bool strict_tri(f3 n, f3 v0, f3 i0, f3 i1, f3 o, f3 d, float tminp, float& t) {
+    const float dn = (d.x * n.x) + (d.y * n.y) + (d.z * n.z);
+    t = ((n.x * v0.x - n.x * o.x) + (n.y * v0.y - n.y * o.y) + (n.z * v0.z - n.z * o.z)) / dn;
+    const f3 ip = F3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+    const f3 pt = F3(ip.x - v0.x, ip.y - v0.y, ip.z - v0.z);
+    const float x = i0.x * pt.x + i0.y * pt.y + i0.z * pt.z, y = i1.x * pt.x + i1.y * pt.y + i1.z * pt.z;
+    return (dn != 0.0f) & (t >= tminp) & (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);
+}
+#pragma clang fp contract(fast)
+// one strict slot at SceneMem address q of device type 'type' (wave-uniform)
+template <bool LDS>
+__device__ __forceinline__ bool strict_slot(const SceneMem<LDS> M, int type, uint32_t q, f3 o, f3 d, float tminp, float& t) {
+    const float4 g = M.ld4(q), a = M.ld4(q + SLOT_A);
+    if (type == PRIM_PLANE_STRICT) return strict_plane(F3(g), F3(a), o, d, tminp, t);
+    const float4 g1 = M.ld4(q + SLOT_G1), g2 = M.ld4(q + SLOT_G2);
+    if (type == PRIM_TRI_STRICT) return strict_tri(F3(g), F3(a), F3(g1), F3(g2), o, d, tminp, t);
+    const float4 g3 = M.ld4(q + SLOT_G3);
+    return strict_rect(F3(g), F3(g1), F3(g2), F3(a), __float_as_int(g3.z), g.w, g1.w, g3.x, g2.w, g3.y, o, d, tminp, t);
+}
+
 // Closest hit, 03 Scene::intersectsRay / 04 scene::List::intersectsRay (03 Utils.h:255-271, 04 Utils.h:362-390):
 // tMax shrinks to the closest hit so far and a test accepts t <= tMax, so the LAST element wins exact ties.
 // closest_hit_runs walks n_runs runs whose first slot is at SceneMem address q and updates (closest, best) in place, so a
@@ -265,6 +336,14 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
                 float4 g = M.ld4(q);
                 float t = (g.w - dot(F3(g), o)) * rcp_fast(dot(F3(g), d));
                 bool hit = (t >= tminp) & (t <= closest);
+                closest = hit ? t : closest; best = hit ? q : best;
+            }
+        } else if (is_strict_type(type)) {   // coplanar with a slot of another kind: the reference's own operation sequence (see PRIM_*_STRICT)
+            const uint32_t step = type == PRIM_PLANE_STRICT ? SLOT_BYTES : 2 * SLOT_BYTES;
+            const f3 ds = strict_dir(d);
+            for (int i = 0; i < count; ++i, q += step) {
+                float t;
+                const bool hit = strict_slot<LDS>(M, type, q, o, ds, tminp, t) & (t <= closest);
                 closest = hit ? t : closest; best = hit ? q : best;
             }
         } else {

@@ -68,11 +68,21 @@ std::string affine3(const float4& a, const char* v) {
     return e;
 }
 
+// A PRIM_*_STRICT slot (rt_device.h): the call of its strict_* test with the slot's numbers as literals; sets 't', yields "passes for tMax = inf".
+std::string strict_call(int type, const float4* g) {
+    if (type == PRIM_PLANE_STRICT) return "strict_plane(" + v3(g[0]) + ", " + v3(g[1]) + ", o, ds, tminp, t)";
+    if (type == PRIM_TRI_STRICT) return "strict_tri(" + v3(g[0]) + ", " + v3(g[1]) + ", " + v3(g[4]) + ", " + v3(g[5]) + ", o, ds, tminp, t)";
+    int ax; memcpy(&ax, &g[6].z, 4);
+    return "strict_rect(" + v3(g[0]) + ", " + v3(g[4]) + ", " + v3(g[5]) + ", " + v3(g[1]) + ", " + std::to_string(ax) + ", " + lit(g[0].w) + ", " + lit(g[4].w) + ", " +
+           lit(g[6].x) + ", " + lit(g[5].w) + ", " + lit(g[6].y) + ", o, ds, tminp, t)";
+}
+
 // One block per primitive; K = byte offset of its slot in the slot section + SLOT_BYTES (0 stays "no hit").
 std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<int4>& sruns) {
     std::string s;
     s += "namespace rt {\n__device__ __forceinline__ uint32_t closest_hit_jit(f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {\n";
     s += "    uint32_t best = 0U;\n    float closest = tmax;\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d; (void)tmin; (void)tminp;\n";
+    for (const int4& run : sruns) if (is_strict_type(run.x)) { s += "    const f3 ds = strict_dir(d);\n"; break; }
     size_t q = 0;   // float4 index into slots
     for (const int4& run : sruns) {
         for (int i = 0; i < run.z; ++i) {
@@ -90,6 +100,8 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
                 s += "    { float t = (" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + "; bool hit = (t >= tminp) & (t <= closest); " + take;
             } else if (run.x == PRIM_PLANE) {
                 s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); bool hit = (t >= tminp) & (t <= closest); " + take;
+            } else if (is_strict_type(run.x)) {
+                s += "    { float t; bool hit = " + strict_call(run.x, g) + "; hit = hit & (t <= closest); " + take;
             } else {   // rectangle / triangle: wide slot, G1..G3 behind the shading records
                 const float4 &g1 = g[4], &g2 = g[5], &g3 = g[6];
                 s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); f3 p = madd(d, t, o);\n";
@@ -99,7 +111,7 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
                 else                    s += "      bool in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);\n";
                 s += "      bool hit = (t >= tminp) & (t <= closest) & in; " + take;
             }
-            q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
+            q += is_wide_type(run.x) ? 8 : 4;
         }
     }
     s += "    t_out = closest;\n    return best;\n}\n";
@@ -113,6 +125,7 @@ std::string gen_any_hit(const std::vector<float4>& slots, const std::vector<int4
     // changes nothing (that element occludes), and the sphere rule "origin inside, far root beyond tMax" occludes in both.
     s += "__device__ __forceinline__ bool any_hit_jit(f3 o, f3 d, float tmin, float tminp, float tmax) {\n";
     s += "    bool occ = false;\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d; (void)tmin; (void)tminp;\n";
+    for (const int4& run : sruns) if (is_strict_type(run.x)) { s += "    const f3 ds = strict_dir(d);\n"; break; }
     for (const int4& run : sruns) {
         for (int i = 0; i < run.z; ++i) {
             const float4* g = &slots[q];
@@ -126,6 +139,8 @@ std::string gen_any_hit(const std::vector<float4>& slots, const std::vector<int4
                 s += "    { float t = (" + lit(g[0].x) + " - o." + ax + ") * inv_d." + ax + "; occ |= (t >= tminp) & (t <= tmax); }\n";
             } else if (run.x == PRIM_PLANE) {
                 s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); occ |= (t >= tminp) & (t <= tmax); }\n";
+            } else if (is_strict_type(run.x)) {
+                s += "    { float t; bool hit = " + strict_call(run.x, g) + "; occ |= hit & (t <= tmax); }\n";
             } else {
                 const float4 &g1 = g[4], &g2 = g[5], &g3 = g[6];
                 s += "    { float t = (" + lit(g[0].w) + " - " + dot3(g[0], "o") + ") * rcp_fast(" + dot3(g[0], "d") + "); f3 p = madd(d, t, o);\n";
@@ -135,7 +150,7 @@ std::string gen_any_hit(const std::vector<float4>& slots, const std::vector<int4
                 else                    s += "      bool in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);\n";
                 s += "      occ |= (t >= tminp) & (t <= tmax) & in; }\n";
             }
-            q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
+            q += is_wide_type(run.x) ? 8 : 4;
         }
     }
     s += "    return occ;\n}\n} // namespace rt\n";
@@ -168,7 +183,7 @@ bool sphere_interior_is_empty(const std::vector<float4>& slots, const std::vecto
     for (const int4& run : sruns) {
         for (int i = 0; i < run.z; ++i) {
             const float4* g = &slots[q];
-            const size_t step = (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
+            const size_t step = is_wide_type(run.x) ? 8 : 4;
             if (q != q0) {
                 double dist;      // a lower bound of the distance from the sphere's centre to the other primitive's surface
                 if (is_sphere_type(run.x)) {
@@ -208,7 +223,7 @@ std::string gen_closest_hit_v2(const std::vector<float4>& slots, const std::vect
             const float4* g = &slots[q];
             const std::string K = std::to_string(q * 16 + SLOT_BYTES) + "U";
             if (skip && ((is_sphere_type(run.x) && strchr(skip, 's')) || (is_aaplane_type(run.x) && strchr(skip, 'a')) || ((run.x == PRIM_RECT || run.x == PRIM_TRI) && strchr(skip, 'r')))) {
-                q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4; continue; }
+                q += is_wide_type(run.x) ? 8 : 4; continue; }
             if (is_sphere_type(run.x)) {
                 s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
                 s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
@@ -235,7 +250,7 @@ std::string gen_closest_hit_v2(const std::vector<float4>& slots, const std::vect
                 else                    s += "      bool in = (x >= 0.0f) & (y >= 0.0f) & (x + y <= 1.0f);\n";
                 s += "      uint32_t k = in ? __float_as_uint(t) - " + C + " : 0xffffffffU;" + take(K);
             }
-            q += (run.x == PRIM_RECT || run.x == PRIM_TRI) ? 8 : 4;
+            q += is_wide_type(run.x) ? 8 : 4;
         }
     }
     s += "    t_out = __uint_as_float(ck + " + C + ");\n    return best;\n}\n";
@@ -289,7 +304,9 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     // generation 1 (float compares) is the default: on MI355X it measured 2 % faster than generation 2 (unsigned keys) although
     // the latter has the cheaper instruction mix on paper; RT_MI355_JIT_GEN=2 selects generation 2 (same image, bit for bit)
     const char* gen_env = getenv("RT_MI355_JIT_GEN");
-    const bool gen2 = variant != RT_JIT_WHITTED_SOFT && gen_env && gen_env[0] == '2' && tmin >= 0.0f && tmax > tmin && std::isfinite(tmax);
+    bool has_strict = false;      // slots in the reference's operation sequence (rt_device.h PRIM_*_STRICT): generation 1 only
+    for (const int4& r : sruns) has_strict = has_strict || is_strict_type(r.x);
+    const bool gen2 = variant != RT_JIT_WHITTED_SOFT && gen_env && gen_env[0] == '2' && tmin >= 0.0f && tmax > tmin && std::isfinite(tmax) && !has_strict;
     src += (gen2 ? gen_closest_hit_v2(slots, sruns, tmin, tmax) : gen_closest_hit(slots, sruns)) + gen_any_hit(slots, sruns);
     const char* entry = variant == RT_JIT_WHITTED_SOFT ? "k_whitted_jit" : "k_path_jit";
     if (variant == RT_JIT_WHITTED_SOFT)   // 02: the generated query serves the shadow samples of whitted_body<true>
