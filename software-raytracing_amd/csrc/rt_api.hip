@@ -25,7 +25,7 @@ using namespace rt;
 // the symbol, not a device address: rt_create() asks hipGetSymbolAddress for the address on ITS device (each GPU has its own
 // copy at its own address) and keeps it in g_scratch_ptr[device]; host code only ever uses that pointer.
 #define RT_NOALLOC_SCENE_BYTES   (64u * 1024u)                 /* flattened scene incl. materials: about 700 spheres/planes */
-#define RT_NOALLOC_COUNTER_BYTES (RT_COUNTER_WORDS * 8u)
+#define RT_NOALLOC_COUNTER_BYTES (RT_COUNTER_ALLOC_WORDS * 8u)
 #define RT_NOALLOC_PARTIAL_BYTES (32u * 1024u * 1024u)         /* per-slice partial images (width*height*16 B each) */
 #define RT_NOALLOC_SCRATCH_BYTES (RT_NOALLOC_SCENE_BYTES + RT_NOALLOC_COUNTER_BYTES + RT_NOALLOC_PARTIAL_BYTES)
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
@@ -122,6 +122,7 @@ struct HostScene {
 
 struct rt_ctx {
     int device = 0;
+    int n_cus = 256;                              // compute units: sizes the persistent grid of the item kernels
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_scene_use = nullptr;            // recorded behind the last work that reads scene_buf / h_stage, on whichever stream it ran
@@ -134,6 +135,7 @@ struct rt_ctx {
     unsigned long long* h_counters = nullptr;     // pinned
     std::string jit_note;                         // why the last path render was not scene-specialised ("" = it was)
     int last_path_kernel = -1;                    // 3 BVH walk, 2 specialised, 1 generic LDS-resident, 0 tiled / global
+    int last_path_form = -1, last_unit_log2 = 0;  // RT_FORM_* of the last path render; item form: log2 of the pixels per unit
     int last_whitted_kernel = -1;                 // 2 specialised (02 only), 1 generic
     void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned scene staging
     uint64_t pending_samples = 0;
@@ -631,7 +633,7 @@ int prepare_scene(rt_ctx* c, const rt_scene* scene, int variant, float tmin, boo
 }
 
 int begin_timed(rt_ctx* c, hipStream_t st, unsigned long long* d_counters = nullptr) {
-    HIPCHK(c, hipMemsetAsync(d_counters ? d_counters : c->d_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), st));
+    HIPCHK(c, hipMemsetAsync(d_counters ? d_counters : c->d_counters, 0, RT_COUNTER_ALLOC_WORDS * sizeof(unsigned long long), st));      // ray counters + the item kernels' work counter
     HIPCHK(c, hipEventRecord(c->ev0, st));
     return RT_OK;
 }
@@ -650,23 +652,33 @@ int check_ctx(rt_ctx* c) {
     return RT_OK;
 }
 
+// Legacy forms (path_body, tiled, BVH walk: one lane per pixel): sample slices when the image alone cannot fill the chip.
 int pick_slices(int width, int height, int n_samples) {
     // enough threads to fill 256 CUs x 2048 lanes several times over; one slice at 4K
     long long pixels = (long long)width * height;
     long long target = 4LL * 256 * 2048;
     int s = (int)((target + pixels - 1) / pixels);
     if (s < 1) s = 1;
-    // long frames: a block that renders all samples of its tile lives for tens of milliseconds (17 ms at 4K / 1024 spp) and the
-    // launch ends with most CUs waiting for the last of them.  At most 128 samples per block, up to 8 slices and 2 GiB of
-    // partial images: 268.5 -> 263.9 ms on the headline frame (tools/slices_probe.sh); no effect at 256 spp, and on short
-    // frames more slices only cost (03 at 1080p / 256 spp: 6.2 ms with 2 slices, 6.8 with 8)
-    int by_length = (n_samples + 127) / 128;
-    if (by_length > 8) by_length = 8;
-    while (by_length > s && (long long)by_length * pixels * 16 > (2LL << 30)) --by_length;
-    if (by_length > s) s = by_length;
     if (s > n_samples) s = n_samples;
     if (s > 64) s = 64;
     return s < 1 ? 1 : s;
+}
+// Item form (path_items_body): a unit of work is 2^unit_log2 consecutive pixels x the sample range.  Long frames are cut into
+// units by shrinking the PIXEL group, not the sample range - at most RT_UNIT_ITEMS paths per unit whatever the frame (16 pixels
+// at 1024 spp, 64 at <= 256) - so every pixel keeps one owner and no partial image exists.  A wave drains a unit before it takes
+// the next (its last paths run in a partly filled wave), so a unit must be long against one path - at least RT_UNIT_MIN_ITEMS,
+// 64 paths per lane - and there must be enough units to occupy the chip; frames too small for both (784x561 at 32 spp is 0.5 ms of
+// work) keep one lane per pixel and sample slices (path_body), which fill the chip with fewer paths per wave.
+constexpr int RT_UNIT_ITEMS = 16384, RT_UNIT_MIN_ITEMS = 4096;
+struct ItemPlan { bool ok; int unit_log2, n_groups; };
+ItemPlan plan_items(int width, int height, int n_samples, int n_cus) {
+    const long long pixels = (long long)width * height, waves = (long long)n_cus * 32;      // resident waves at 8 blocks per CU
+    int k = 6;
+    while (k > 0 && ((long long)n_samples << k) > RT_UNIT_ITEMS) --k;
+    while (k > 0 && (pixels >> k) < 2 * waves && ((long long)n_samples << (k - 1)) >= RT_UNIT_MIN_ITEMS) --k;
+    ItemPlan p{true, k, (int)((pixels + (1 << k) - 1) >> k)};
+    p.ok = ((long long)n_samples << k) >= RT_UNIT_MIN_ITEMS && p.n_groups >= waves;
+    return p;
 }
 
 // ---- device group: RCCL bound at run time ------------------------------------------------------------------------------
@@ -719,8 +731,9 @@ rt_ctx* rt_create(int32_t device_id) {
     if ((e = hipSetDevice(dev)) != hipSuccess) { g_create_error = hipGetErrorString(e); return nullptr; }
     rt_ctx* c = new rt_ctx();
     c->device = dev;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
-              hipEventCreate(&c->ev1) == hipSuccess && hipEventCreateWithFlags(&c->ev_scene_use, hipEventDisableTiming) == hipSuccess && hipMalloc((void**)&c->d_counters, RT_COUNTER_WORDS * sizeof(unsigned long long)) == hipSuccess &&
+              hipEventCreate(&c->ev1) == hipSuccess && hipEventCreateWithFlags(&c->ev_scene_use, hipEventDisableTiming) == hipSuccess && hipMalloc((void**)&c->d_counters, RT_COUNTER_ALLOC_WORDS * sizeof(unsigned long long)) == hipSuccess &&
               hipHostMalloc((void**)&c->h_counters, RT_COUNTER_WORDS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
     if (!ok) { g_create_error = "failed to create stream/events/counters"; rt_destroy(c); return nullptr; }
     {   // set-up of the allocation-free entry point, once per device, with that device current
@@ -890,18 +903,45 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     rotation_mat(cam->orientation_deg, A.r);
     A.px = cam->position[0]; A.py = cam->position[1]; A.pz = cam->position[2];
     int n_samples = s1 - s0;
-    int slices = n_samples > 0 ? pick_slices(width, height, n_samples) : 1;
-    if (const char* e = getenv("RT_MI355_SLICES")) {      // experiment switch: sample slices per frame (shorter blocks, a shorter tail; costs the partial images)
+    size_t npx = (size_t)width * height;
+    // Which form of the bounce loop.  LDS-resident scenes (the specialised builds included) take the ITEM form (path_items_body:
+    // persistent waves, a work counter, lanes decoupled from pixels, fixed-point per-pixel sums) unless something it
+    // cannot do is asked for: material colours outside [0, 1] (lights: [0, 1e6]) - its sums are unsigned 32.32 fixed point.
+    // RT_MI355_PATH=r or debug flag 512 keeps per-lane regeneration (path_body), RT_MI355_PATH=q or debug flag 256 selects the
+    // queue form (path_queue_body: workgroup-level ray-queue compaction through LDS; it lost its A/B).  Scenes
+    // beyond LDS (k_path_tiled) and the BVH walk keep one lane per pixel.
+    const char* pk = getenv("RT_MI355_PATH");
+    bool colours_ok = true;
+    for (int m = 0; colours_ok && m < scene->n_materials; ++m)
+        for (int k = 0; k < 3; ++k) {
+            const float v = scene->materials[m].albedo[k];
+            colours_ok = colours_ok && v >= 0.0f && v <= (scene->materials[m].type == RT_MAT_LIGHT ? 1e6f : 1.0f);
+        }
+    const bool lds_fit = (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES;
+    A.queue = (((pk && pk[0] == 'q') || (c->debug_flags & 256)) && !noalloc && !accel && !(c->debug_flags & (2 | 4)) && lds_fit && colours_ok) ? 1 : 0;
+    A.items = (!A.queue && !accel && lds_fit && colours_ok && !(pk && pk[0] == 'r') && !(c->debug_flags & 512) && n_samples > 0) ? 1 : 0;
+    int slices = 1;
+    if (A.items) {
+        ItemPlan ip = plan_items(width, height, n_samples, c->n_cus);
+        if (const char* e = getenv("RT_MI355_UNIT_LOG2")) {      // experiment switch: item form with 2^v pixels per unit, whatever the frame
+            const int v = atoi(e);
+            if (v >= 0 && v <= 6) { ip.ok = true; ip.unit_log2 = v; ip.n_groups = (int)((npx + ((size_t)1 << v) - 1) >> v); }
+        }
+        if (c->debug_flags & 1024) ip.ok = true;                 // tests: item form on small frames too
+        A.items = ip.ok ? 1 : 0; A.unit_log2 = ip.unit_log2; A.n_groups = ip.n_groups;
+    }
+    if (!A.items && n_samples > 0) slices = pick_slices(width, height, n_samples);
+    if (const char* e = getenv("RT_MI355_SLICES")) {      // experiment switch: sample slices per frame
         const int v = atoi(e);
         if (v >= 1 && v <= 64 && n_samples > 0) slices = v < n_samples ? v : n_samples;
     }
-    size_t npx = (size_t)width * height;
     if (noalloc) {   // the partial images must fit the fixed scratch: fewer slices, or none (the kernel then writes d_accum directly)
         const size_t fit = RT_NOALLOC_PARTIAL_BYTES / (npx * sizeof(float4));
         if ((size_t)slices > fit) slices = fit >= 2 ? (int)fit : 1;
     }
     A.slice_len = n_samples > 0 ? (n_samples + slices - 1) / slices : 1;
     slices = n_samples > 0 ? (n_samples + A.slice_len - 1) / A.slice_len : 1;
+    A.n_units = A.items ? A.n_groups * slices : 0;
     float4* target = (float4*)d_accum;
     float4* partial = nullptr;
     if (slices > 1 && noalloc) partial = reinterpret_cast<float4*>(c->scratch_dev + RT_NOALLOC_SCENE_BYTES + RT_NOALLOC_COUNTER_BYTES);
@@ -909,28 +949,18 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     if (slices > 1) target = partial;
     // small scenes: the scene query compiled for THIS scene (literal operands, no loops); debug flag 8 or RT_MI355_JIT=0 keeps
     // the generic kernel, debug flag 16 or RT_MI355_JIT=2 specialises at the first render (A/B and parity tests); an unavailable hiprtc is not an error, the generic kernel renders the same image
-    // Which form of the bounce loop (LDS-resident scenes).  Default: per-lane regeneration (path_body), the faster one on every
-    // configuration measured.  The queue form (path_queue_body: workgroup-level ray-queue compaction through
-    // LDS, fixed-point sums) is selected by RT_MI355_PATH=q or debug flag 256, unless something it cannot do is asked for:
-    // per-pixel ray counts (debug flag 4), negative or huge material colours (its sums are unsigned 32.32 fixed point).
-    {
-        const char* pk = getenv("RT_MI355_PATH");
-        bool ok = ((pk && pk[0] == 'q') || (c->debug_flags & 256)) && !noalloc && !accel && !(c->debug_flags & (2 | 4)) && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES;
-        for (int m = 0; ok && m < scene->n_materials; ++m)
-            for (int k = 0; k < 3; ++k) ok = ok && scene->materials[m].albedo[k] >= 0.0f && scene->materials[m].albedo[k] < 1e9f;
-        A.queue = ok ? 1 : 0;
-    }
     hipFunction_t jit = nullptr;
     const char* jit_env = getenv("RT_MI355_JIT");
     c->jit_note.clear();
-    if (!noalloc && !accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES &&
+    if (!noalloc && !accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && lds_fit &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
-        jit = jit_path_kernel(p->variant, H.slots, H.sruns, p->t_min, p->t_max, A.queue != 0, c->jit_note);
+        jit = jit_path_kernel(p->variant, H.slots, H.sruns, p->t_min, p->t_max, A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : RT_FORM_REGEN, c->jit_note);
     if (noalloc) c->jit_note = "allocation-free entry point: generic kernel";
     if ((rc = begin_timed(c, st, counters))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
     c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));
+    c->last_path_form = A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : RT_FORM_REGEN; c->last_unit_log2 = A.items ? A.unit_log2 : 0;
     if (accel) { c->jit_note = "BVH walk (RT_OPT_ACCEL)"; launch_path_bvh(p->variant, D, A, target, slices, counters, st); }
-    else launch_path(p->variant, D, A, target, slices, counters, st, jit);
+    else launch_path(p->variant, D, A, target, slices, counters, st, jit, c->n_cus * 8);
     HIPCHK(c, hipGetLastError());
     if (slices > 1) { launch_sum_slices(partial, (int)npx, slices, (float4*)d_accum, st); HIPCHK(c, hipGetLastError()); }
     c->pending_samples = (uint64_t)npx * (uint64_t)n_samples;
@@ -977,7 +1007,7 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
     if (p->shadow_samples > 0 && !(c->debug_flags & 8) && !(jit_env && jit_env[0] == '0') &&
         jit_wanted(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, (double)width * height * p->shadow_samples * (scene->n_lights > 0 ? scene->n_lights : 1),
                    (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
-        jit = jit_path_kernel(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, 0.01f, 1000.0f, false, c->jit_note);
+        jit = jit_path_kernel(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, 0.01f, 1000.0f, RT_FORM_REGEN, c->jit_note);
     c->last_whitted_kernel = jit ? 2 : 1;
     if ((rc = begin_timed(c, st))) return rc;      // after a possible compile
     launch_whitted(p->shadow_samples > 0, D, A, (float4*)d_color, c->d_counters, st, jit);
@@ -1196,6 +1226,9 @@ int32_t rt_debug_last_path_kernel(const rt_ctx* c, char* note, int32_t cap) {
     return c->last_path_kernel;
 }
 int32_t rt_debug_last_whitted_kernel(const rt_ctx* c) { return c ? c->last_whitted_kernel : -1; }
+// which form of the bounce loop rendered the last path image: 0 per-lane regeneration (one lane per pixel), 1 queue form, 2 item
+// form (persistent waves + work counter); unit_log2: item form, log2 of the pixels per unit of work
+int32_t rt_debug_last_path_form(const rt_ctx* c, int32_t* unit_log2) { if (!c) return -1; if (unit_log2) *unit_log2 = c->last_unit_log2; return c->last_path_form; }
 // variant 3 / 4: the path kernels; 2: the 02 kernel (a Whitted scene)
 int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, int32_t cap) {
     HostScene H;
@@ -1203,7 +1236,7 @@ int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, i
     int rc = compile_scene(nullptr, scene, (variant & 7) == RT_JIT_WHITTED_SOFT ? 0 : (variant & 7), tmin, H);
     if (rc) return rc;
     std::string n;
-    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, tmin, 1000.0f, (variant & 8) != 0, n);
+    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, tmin, 1000.0f, (variant & 8) ? RT_FORM_QUEUE : (variant & 16) ? RT_FORM_ITEMS : RT_FORM_REGEN, n);
     if (note && cap > 0) { strncpy(note, n.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
     return fn ? 1 : 0;
 }

@@ -13,6 +13,10 @@ namespace rt {
 // frame takes less), so the atomics are spread over banks (bank = block index mod RT_COUNTER_BANKS), summed on the host.
 #define RT_COUNTER_BANKS 256
 #define RT_COUNTER_WORDS (2 * RT_COUNTER_BANKS)
+// behind the ray counters, in the same allocation (cleared with them before every launch): the work counter of the item
+// kernels (path_items_body, rt_path_device.h) - the index of the next unit of work a wave may take
+#define RT_WORK_COUNTER RT_COUNTER_WORDS
+#define RT_COUNTER_ALLOC_WORDS (RT_COUNTER_WORDS + 8)
 
 struct PathArgs {
     int width, height;
@@ -23,6 +27,9 @@ struct PathArgs {
     int regen_threshold;            // idle lanes per wave that trigger a regeneration pass
     int debug_flags;                // bit 1 (2): no LDS staging (A/B switch); bit 2 (4): accumulator w = rays of the pixel
     int queue;                      // LDS-resident scenes: the queue form of the bounce loop (path_queue_body) instead of per-lane regeneration
+    // item form (path_items_body): a unit of work = 2^unit_log2 consecutive pixels (row-major) x one sample slice; n_groups
+    // pixel groups per slice, n_units = n_groups x slices units in all, handed out through counters[RT_WORK_COUNTER]
+    int items, unit_log2, n_groups, n_units;
     uint32_t seed;
     float t_min, t_min_pos, t_max;  // t_min_pos = max(t_min, smallest positive float): "t > 0 && t >= tMin" in one compare
     float inv_w2, inv_h2, kx, ky;   // 2/w, 2/h, tan(fov/2)*w/h, tan(fov/2)

@@ -11,6 +11,8 @@ constexpr int RT_JIT_WHITTED_SOFT = 2;   // 'variant' of the 02 kernel (3 and 4 
 // Policy: whether this render should use (and, if need be, compile) the specialised kernel; counts sightings of the scene.
 bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, double job_samples, bool force, std::string& note);
 // tmin / tmax: the range of the path query (literals of the generated code; ignored by the 02 kernel, whose shadow rays carry their own)
-hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, bool queue, std::string& note);
-// queue: the kernel body is path_queue_body (workgroup-level ray-queue compaction) instead of path_body (per-lane regeneration)
+hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note);
+// form: which body the kernel wraps - RT_FORM_REGEN path_body (per-lane regeneration), RT_FORM_QUEUE path_queue_body (workgroup-level
+// ray-queue compaction), RT_FORM_ITEMS path_items_body (persistent waves, work counter, lanes decoupled from pixels)
+enum { RT_FORM_REGEN = 0, RT_FORM_QUEUE = 1, RT_FORM_ITEMS = 2 };
 }

@@ -288,7 +288,7 @@ bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector
     return false;
 }
 
-hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, bool queue, std::string& note) {
+hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note) {
     size_t n_prims = 0;
     for (const int4& r : sruns) n_prims += (size_t)r.z;
     if (n_prims == 0 || n_prims > RT_JIT_MAX_PRIMS) { note = "scene has " + std::to_string(n_prims) + " slots (specialised up to " + std::to_string(RT_JIT_MAX_PRIMS) + ")"; return nullptr; }
@@ -316,7 +316,7 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     else
         src += std::string(kSrcPath) +
             "\nextern \"C\" __global__ __launch_bounds__(256) void k_path_jit(rt::DevScene SD, rt::PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
-            "    rt::path_" + std::string(queue ? "queue_" : "") + "body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
+            "    rt::path_" + std::string(form == RT_FORM_QUEUE ? "queue_" : form == RT_FORM_ITEMS ? "items_" : "") + "body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
     int dev = 0; (void)hipGetDevice(&dev);
     const auto key = std::make_pair(dev, fnv1a(src));
     std::lock_guard<std::mutex> lock(g_mu);

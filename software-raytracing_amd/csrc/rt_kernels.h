@@ -10,7 +10,8 @@ namespace rt {
 struct DevScene;
 
 // jit: scene-specialised kernel for this scene (rt_jit.h) or nullptr
-void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit);
+// items_grid_blocks: blocks of the persistent grid of the item form (A.items): what the device holds at once
+void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit, int items_grid_blocks);
 // optional BVH walk (rt_bvh.h, rt_bvh_device.h)
 void launch_path_bvh(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st);
 void launch_add_image(float4* dst, const float4* src, int n_pixels, hipStream_t st);

@@ -7,6 +7,7 @@
 #include "rt_path_device.h"
 #include "rt_whitted_device.h"
 #include "rt_bvh_device.h"
+#include <algorithm>
 
 namespace rt {
 
@@ -28,16 +29,32 @@ __global__ __launch_bounds__(256) void k_path_q(DevScene SD, PathArgs A, float4*
     path_queue_body<VARIANT, LDS, EARLY>(SD, A, out, counters);
 }
 
+// Item form (rt_path_device.h): persistent waves pulling (pixel group x sample slice) units from a work counter.
+template <int VARIANT, bool LDS, bool EARLY = false>
+__global__ __launch_bounds__(256) void k_path_items(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    path_items_body<VARIANT, LDS, EARLY>(SD, A, out, counters);
+}
+
 template <int VARIANT>
-static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
+static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit, int items_grid_blocks) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 15) / 16), n_slices);
     size_t bytes = (size_t)S.total_f4 * sizeof(float4);
     const bool queue = A.queue && bytes <= RT_LDS_SCENE_MAX_BYTES;      // queue form: LDS-resident scenes
-    if (jit && bytes <= RT_LDS_SCENE_MAX_BYTES) {   // scene-specialised k_path<VARIANT, true> / k_path_q<VARIANT, true> (rt_jit.hip)
+    // item form: a persistent grid - as many blocks as the chip holds (the host's estimate; more would only find the counter exhausted), at most one wave per unit
+    const bool items = A.items && !queue;
+    if (items) grid = dim3((unsigned)std::max(1, std::min(items_grid_blocks, (A.n_units + 3) / 4)), 1);
+    if (jit && bytes <= RT_LDS_SCENE_MAX_BYTES) {   // scene-specialised k_path<VARIANT, true> / k_path_items / k_path_q (rt_jit.hip)
         DevScene s = S; PathArgs a = A;
         void* params[] = {&s, &a, &out, &counters};
-        if (hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)(bytes + (queue ? RT_Q_WS_BYTES : 0)), st, params, nullptr) == hipSuccess) return;
+        if (hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)(bytes + (queue ? RT_Q_WS_BYTES : 0) + (items ? 4 * RT_ITEMS_WAVE_BYTES : 0)), st, params, nullptr) == hipSuccess) return;
         (void)hipGetLastError();   // could not launch the specialised kernel: the generic one below renders the same image
+    }
+    if (items) {
+        const size_t ws = 4 * RT_ITEMS_WAVE_BYTES;
+        if (A.debug_flags & 2)                hipLaunchKernelGGL((k_path_items<VARIANT, false>), grid, dim3(256), ws, st, S, A, out, counters);
+        else if (S.slot_bytes > 64 * 64)      hipLaunchKernelGGL((k_path_items<VARIANT, true, true>), grid, dim3(256), bytes + ws, st, S, A, out, counters);
+        else                                  hipLaunchKernelGGL((k_path_items<VARIANT, true>), grid, dim3(256), bytes + ws, st, S, A, out, counters);
+        return;
     }
     if (queue && !(A.debug_flags & 2)) {
         if (S.slot_bytes > 64 * 64) hipLaunchKernelGGL((k_path_q<VARIANT, true, true>), grid, dim3(256), bytes + RT_Q_WS_BYTES, st, S, A, out, counters);
@@ -50,9 +67,9 @@ static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int
     else if (bytes <= RT_LDS_SCENE_MAX_BYTES) hipLaunchKernelGGL((k_path<VARIANT, true>), grid, dim3(256), bytes, st, S, A, out, counters);  // small scene: LDS-resident
     else                                     hipLaunchKernelGGL((k_path_tiled<VARIANT>), grid, dim3(256), RT_TILE_BYTES + SLOT_BYTES, st, S, A, out, counters);   // large scene: LDS-tiled
 }
-void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
-    if (variant == 3) launch_path_v<3>(S, A, out, n_slices, counters, st, jit);
-    else              launch_path_v<4>(S, A, out, n_slices, counters, st, jit);
+void launch_path(int variant, const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit, int items_grid_blocks) {
+    if (variant == 3) launch_path_v<3>(S, A, out, n_slices, counters, st, jit, items_grid_blocks);
+    else              launch_path_v<4>(S, A, out, n_slices, counters, st, jit, items_grid_blocks);
 }
 
 // Optional BVH walk (rt_set_option(RT_OPT_ACCEL, RT_ACCEL_BVH)): same bounce loop, the scene query walks a tree.

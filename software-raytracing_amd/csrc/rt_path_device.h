@@ -21,11 +21,12 @@ struct PathLane {
     int depth, s_next, n_started;
     unsigned int rays;
     bool alive;
+    uint32_t pl, acc0;        // item form only: the path's pixel within its unit, and the LDS address of the unit's fixed-point sums (wave-uniform)
 };
 __device__ __forceinline__ PathLane lane_init(int s_next) {
     PathLane L;
     L.o = F3(0, 0, 0); L.d = F3(0, 0, -1); L.thr = F3(0, 0, 0); L.acc = F3(0, 0, 0);
-    L.skey = 0; L.rkey = 0; L.depth = 0; L.s_next = s_next; L.n_started = 0; L.rays = 0; L.alive = false;
+    L.skey = 0; L.rkey = 0; L.depth = 0; L.s_next = s_next; L.n_started = 0; L.rays = 0; L.alive = false; L.pl = 0; L.acc0 = 0;
     return L;
 }
 
@@ -56,14 +57,31 @@ __device__ __forceinline__ void regenerate(const PathArgs& A, int px, int py, ui
     const unsigned long long m_alive = __builtin_amdgcn_ballot_w64((L).alive), \
                              m_want = ~m_alive & __builtin_amdgcn_ballot_w64((L).s_next < (s_end))   /* the compare's mask is fresh: no round trip through a VGPR */
 
+// Radiance of a path that ends (the sky of 03, a light's front face in 04).  DEPOSIT = false: into the lane's own running sums
+// (the lane owns a pixel).  DEPOSIT = true (item form): into the pixel's 32.32 fixed-point sums in LDS - integer addition is
+// order-independent, so the frame does not depend on which lane traced which path.  Contributions are taken as >= 0 and < 2^32.
+__device__ __forceinline__ unsigned long long to_fixed_32_32(float x) {
+    const uint32_t hi = (uint32_t)x;                                           // saturating, NaN -> 0
+    return ((unsigned long long)hi << 32) | (uint32_t)(__builtin_amdgcn_fractf(x) * 4294967296.0f);
+}
+template <bool DEPOSIT>
+__device__ __forceinline__ void add_radiance(PathLane& L, f3 v) {
+    if (DEPOSIT) {
+        RT_LDS_AS unsigned long long* a = (RT_LDS_AS unsigned long long*)(uintptr_t)(L.acc0 + L.pl * 24U);
+        __hip_atomic_fetch_add(a, to_fixed_32_32(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(a + 1, to_fixed_32_32(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(a + 2, to_fixed_32_32(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else L.acc = L.acc + v;
+}
+
 // One bounce after the scene query: miss / emit / scatter (TraceTay of 03 Main.cpp:392-435, 04 Main.cpp:447-502).
 // hit = SceneMem address of the winning slot (unused when miss), t = its distance.
-template <int VARIANT, bool LDS>
+template <int VARIANT, bool LDS, bool DEPOSIT = false>
 __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, uint32_t mats0, bool miss, uint32_t hit, float t, PathLane& L) {
     if (miss) {
         if (VARIANT == 3) {   // sky: Mix(white, (0.5,0.7,1), 0.5*(d.y+1)) (03 Main.cpp:430-432)
             float h = 0.5f * (L.d.y + 1.0f);
-            L.acc = L.acc + L.thr * F3(fmaf(-0.5f, h, 1.0f), fmaf(-0.3f, h, 1.0f), 1.0f);
+            add_radiance<DEPOSIT>(L, L.thr * F3(fmaf(-0.5f, h, 1.0f), fmaf(-0.3f, h, 1.0f), 1.0f));
         }
         L.alive = false;
     } else {
@@ -147,7 +165,7 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
             }
             ++L.depth;
         } else {
-            if (VARIANT == 4 && mtype == MAT_LIGHT && !back) L.acc = L.acc + L.thr * F3(m0);   // Light.hpp:47-54, Main.cpp:480-483
+            if (VARIANT == 4 && mtype == MAT_LIGHT && !back) add_radiance<DEPOSIT>(L, L.thr * F3(m0));   // Light.hpp:47-54, Main.cpp:480-483
             L.alive = false;
         }
         if (L.depth > A.max_depth) L.alive = false;   // 03 Main.cpp:383-386, 04 Main.cpp:438-441
@@ -204,6 +222,135 @@ __device__ __forceinline__ void path_body(const DevScene& SD, const PathArgs& A,
         out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);
     }
     wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
+}
+
+// =================================================================================================
+// Item form of the bounce loop (K3/K4): persistent waves, a work counter, lanes decoupled from pixels.
+//
+// path_body ties a lane to a pixel: a lane whose pixel is exhausted idles until the slowest pixel of its wave is done, a block
+// lives as long as its slowest wave, long frames need sample slices (partial images in HBM plus a summing pass) to keep the
+// launch tail short.  Here the grid is PERSISTENT (as many blocks as the chip holds) and every WAVE pulls units of work from one
+// global counter until none is left.  A unit = a group of 2^unit_log2 consecutive pixels x the samples of one slice - normally
+// the whole sample range, because a long frame is cut into units by making the pixel group SMALL (8 pixels at 1024 spp) instead
+// of cutting the samples: a unit is then some 8-16 thousand paths whatever the frame, the tail of the launch is one unit long,
+// and each pixel still has exactly one owner, so the sums are stored once, plainly - no partial images, no summing pass, HBM
+// traffic = the algorithmic 16 B per pixel.  Inside a unit the wave's 64 lanes share its (pixel, sample) ITEMS: an idle lane
+// takes the next item whichever pixel it belongs to (rank among the idle lanes by mbcnt, one scalar counter per wave), so no
+// lane waits for another lane's pixel.  A finished path that carries radiance adds it to its pixel's sum in LDS as 32.32 fixed
+// point (ds_add_u64): integer addition is order-independent, so the frame does not depend on which lane traced what - bit for
+// bit the same frame from run to run and for every unit size (contributions are taken as >= 0 and < 2^32, resolution 2^-32;
+// the host selects path_body for scenes with colours outside that).  No barrier after the scene blob is staged: waves are
+// independent.  Same RNG keys (pixel, sample), same camera arithmetic, same query and shading code as path_body: the same
+// paths; only the rounding of the per-pixel sum differs (exact fixed point rounded once vs a running float).
+// =================================================================================================
+#define RT_ITEMS_WAVE_BYTES (64 * 3 * 8 + 64 * 4 + 64 * 8)      /* per wave: fixed-point sums of up to 64 pixels, per-pixel query counts (debug flag 4), pixel table */
+template <int VARIANT, bool LDS, bool EARLY = false>
+__device__ __forceinline__ void path_items_body(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    extern __shared__ float4 smem[];
+    const char* base = reinterpret_cast<const char*>(SD.blob);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t ws_off = 0U;
+    if (LDS) {
+        for (int i = tid; i < SD.total_f4; i += 256) smem[i] = SD.blob[i];
+        __syncthreads();                       // the only barrier: from here on the block's waves run independently
+        base = reinterpret_cast<const char*>(smem);
+        ws_off = (uint32_t)SD.total_f4 * 16U;
+    }
+    char* const ws = reinterpret_cast<char*>(smem) + ws_off + wave * RT_ITEMS_WAVE_BYTES;
+    unsigned long long* const acc = reinterpret_cast<unsigned long long*>(ws);      // [pixel of the group][rgb]
+    uint32_t* const qcount = reinterpret_cast<uint32_t*>(ws + 64 * 3 * 8);
+    uint2* const pixtab = reinterpret_cast<uint2*>(ws + 64 * 3 * 8 + 64 * 4);      // per pixel of the unit: {RNG pixel key, x | y << 16 or ~0 = outside the image}
+    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
+    const SceneMem<LDS> M{base};
+    const uint32_t slots0 = M.at((uint32_t)SD.off_slots * 16U), mats0 = M.at(0U);
+    const int k = A.unit_log2, P = 1 << k;
+    const uint32_t n_pixels = (uint32_t)A.width * (uint32_t)A.height;
+    unsigned int rays = 0;
+
+    for (;;) {
+        // ---- next unit of work: one atomic per wave and unit
+        uint32_t u = 0U;
+        if (lane == 0) u = (uint32_t)atomicAdd(counters + RT_WORK_COUNTER, 1ULL);
+        u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+        if (u >= (uint32_t)A.n_units) break;
+        uint32_t slice = 0U, group = u;
+        if (A.n_units != A.n_groups) { slice = u / (uint32_t)A.n_groups; group = u - slice * (uint32_t)A.n_groups; }
+        const int s_first = A.sample_begin + (int)slice * A.slice_len;
+        const int s_end = min(s_first + A.slice_len, A.sample_end);
+        const uint32_t first_px = group << k;                                  // the group's pixels: first_px .. first_px + P - 1, row-major
+        const uint32_t by = first_px / (uint32_t)A.width, bx = first_px - by * (uint32_t)A.width;      // wave-uniform
+        const uint32_t n_items = (uint32_t)max(s_end - s_first, 0) << k;
+        uint32_t my_pixel = 0xFFFFFFFFU;       // lane i < P looks after pixel i of the group: table entry, zeroed sums, the store at the end
+        if (lane < P) {
+            uint32_t x = bx + (uint32_t)lane, y = by;
+            while (x >= (uint32_t)A.width) { x -= (uint32_t)A.width; ++y; }
+            const uint32_t pixel = y * (uint32_t)A.width + x;
+            const bool inside = pixel < n_pixels;
+            if (inside) my_pixel = pixel;
+            pixtab[lane] = make_uint2(rng_pixel_key(A.seed, pixel), inside ? (x | (y << 16)) : 0xFFFFFFFFU);
+            acc[3 * lane] = 0ULL; acc[3 * lane + 1] = 0ULL; acc[3 * lane + 2] = 0ULL; qcount[lane] = 0U;
+        }
+        __builtin_amdgcn_wave_barrier();       // this wave's LDS operations complete in order; the compiler must keep them so
+        uint32_t next = 0U;                    // wave-uniform: the next item to hand out
+        PathLane L = lane_init(0);
+        L.acc0 = (uint32_t)(uintptr_t)(RT_LDS_AS char*)ws;
+
+        for (;;) {
+            const unsigned long long m_alive = __builtin_amdgcn_ballot_w64(L.alive);
+            const bool left = next < n_items;
+            if (m_alive == 0ULL && !left) break;
+            const unsigned long long m_idle = ~m_alive;
+            if (left && (m_alive == 0ULL || __popcll(m_idle) >= A.regen_threshold)) {
+                // idle lanes take the next items in lane order: (pixel, sample) = (item mod P, item div P)
+                const uint32_t item = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0U));
+                next += (uint32_t)__popcll(m_idle);
+                if (!L.alive && item < n_items) {
+                    L.pl = item & (uint32_t)(P - 1);
+                    const uint2 pt = pixtab[L.pl];
+                    if (pt.y != 0xFFFFFFFFU) {  // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369); same arithmetic as regenerate()
+                        const uint32_t x = pt.y & 0xFFFFU, y = pt.y >> 16;
+                        L.skey = rng_sample_key(pt.x, (uint32_t)s_first + (item >> k));
+                        L.rkey = L.skey + 5U * 0x9E3779B9U;
+                        float bxj = 0.5f, byj = 0.5f;
+                        if (A.jitter) rng_pair(L.skey, 0U, bxj, byj);
+                        float cx = fmaf((float)(int)x + bxj, A.inv_w2, -1.0f) * A.kx;
+                        float cy = -fmaf((float)(int)y + byj, A.inv_h2, -1.0f) * A.ky;
+                        f3 v = F3(cx, cy, -1.0f);
+                        const f3 rv = F3(dot(F3(A.r[0], A.r[1], A.r[2]), v), dot(F3(A.r[3], A.r[4], A.r[5]), v), dot(F3(A.r[6], A.r[7], A.r[8]), v));
+                        L.d = rv * rsq_fast(dot(rv, rv));
+                        L.o = F3(A.px, A.py, A.pz);
+                        L.thr = F3(1, 1, 1);
+                        L.depth = 0;
+                        L.alive = true;
+                    }
+                }
+            }
+            if (L.alive) {
+                // TraceTay: one scene query (03 Main.cpp:392, 04 Main.cpp:447)
+                ++rays;
+                if (A.debug_flags & 4) atomicAdd(&qcount[L.pl], 1U);
+                float t;
+#ifdef RT_JIT_SCENE
+                const uint32_t kk = closest_hit_jit(L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+                const uint32_t hit = kk + (slots0 - SLOT_BYTES);
+                const bool miss = kk == 0U;
+                (void)runs;
+#else
+                uint32_t hit = closest_hit_slots<LDS, EARLY>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+                const bool miss = hit == 0U;
+#endif
+                shade<VARIANT, LDS, true>(M, A, mats0, miss, hit, t, L);      // a path that ends with radiance adds it to its pixel's sums in LDS
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (my_pixel != 0xFFFFFFFFU) {         // fixed point -> float, once per pixel
+            const unsigned long long r = acc[3 * lane], g = acc[3 * lane + 1], b = acc[3 * lane + 2];
+            auto tof = [](unsigned long long v) { return (float)((double)v * (1.0 / 4294967296.0)); };
+            out[(size_t)slice * n_pixels + my_pixel] = make_float4(tof(r), tof(g), tof(b), (A.debug_flags & 4) ? (float)qcount[lane] : (float)max(s_end - s_first, 0));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    wave_add_u64(counters + 2 * ((blockIdx.x * 4 + wave) % RT_COUNTER_BANKS), rays);
 }
 
 // =================================================================================================

@@ -74,6 +74,7 @@ def load():
         L.rt_debug_set_flags.argtypes = [C.c_void_p, C.c_int32]
         L.rt_debug_last_path_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
         L.rt_debug_last_whitted_kernel.argtypes = [C.c_void_p]
+        L.rt_debug_last_path_form.argtypes = [C.c_void_p, P(C.c_int32)]
         _LIB = L
     return _LIB
 
@@ -182,6 +183,11 @@ class Context:
         buf = C.create_string_buffer(2048)
         kind = self.L.rt_debug_last_path_kernel(self.h, buf, 2048)
         return kind, buf.value.decode(errors="replace")
+
+    def last_path_form(self):
+        """(form, unit_log2): 0 one lane per pixel (per-lane regeneration), 1 queue form, 2 item form (persistent waves, work counter)"""
+        k = C.c_int32(0)
+        return self.L.rt_debug_last_path_form(self.h, C.byref(k)), k.value
 
     def last_whitted_kernel(self):
         """2 scene-specialised (02 only), 1 generic"""
