@@ -537,8 +537,10 @@ int fill_and_upload_scene(rt_ctx* c, const HostScene& H, const BlobLayout& L, hi
     memcpy(h + o_slots, H.slots.data(), H.slots.size() * 16);
     for (size_t b : H.slot_mat_fixups) {   // material index -> byte offset of its record in the blob
         float4* B = reinterpret_cast<float4*>(h + o_slots) + b;
-        uint32_t off = (uint32_t)(o_mats + (size_t)__builtin_bit_cast(int, B->w) * 48);
+        const int mi = __builtin_bit_cast(int, B->w);
+        uint32_t off = (uint32_t)(o_mats + (size_t)mi * 48);
         B->w = __builtin_bit_cast(float, off);
+        B[1].w = H.mats[(size_t)mi * 3].w;      // C.w: the material's class (the sorted form classifies a hit by one dword)
     }
     memcpy(h + o_mats, H.mats.data(), H.mats.size() * 16);
     memcpy(h + o_lights, H.lights.data(), H.lights.size() * 16);
@@ -678,6 +680,17 @@ ItemPlan plan_items(int width, int height, int n_samples, int n_cus) {
     while (k > 0 && (pixels >> k) < 2 * waves && ((long long)n_samples << (k - 1)) >= RT_UNIT_MIN_ITEMS) --k;
     ItemPlan p{true, k, (int)((pixels + (1 << k) - 1) >> k)};
     p.ok = ((long long)n_samples << k) >= RT_UNIT_MIN_ITEMS && p.n_groups >= waves;
+    return p;
+}
+
+// Outcome-sorted form (path_sorted_body): the unit belongs to a workgroup of 256 lanes: up to 128 pixels, at least 64 paths per lane.
+ItemPlan plan_sorted(int width, int height, int n_samples, int n_cus) {
+    const long long pixels = (long long)width * height, blocks = (long long)n_cus * 5;
+    int k = 7;
+    while (k > 0 && ((long long)n_samples << k) > 4 * RT_UNIT_ITEMS) --k;
+    while (k > 0 && (pixels >> k) < 2 * blocks && ((long long)n_samples << (k - 1)) >= 4 * RT_UNIT_MIN_ITEMS) --k;
+    ItemPlan p{true, k, (int)((pixels + (1 << k) - 1) >> k)};
+    p.ok = ((long long)n_samples << k) >= 4 * RT_UNIT_MIN_ITEMS && p.n_groups >= blocks;
     return p;
 }
 
@@ -920,6 +933,15 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     const bool lds_fit = (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES;
     A.queue = (((pk && pk[0] == 'q') || (c->debug_flags & 256)) && !noalloc && !accel && !(c->debug_flags & (2 | 4)) && lds_fit && colours_ok) ? 1 : 0;
     A.items = (!A.queue && !accel && lds_fit && colours_ok && !(pk && pk[0] == 'r') && !(c->debug_flags & 512) && n_samples > 0) ? 1 : 0;
+    // The outcome-sorted form (path_sorted_body: the workgroup sorts its paths by what the query found, every wave runs one kind of
+    // work): RT_MI355_PATH=s or debug flag 2048; same eligibility as the item form, blob + exchange buffers within 64 KB of LDS.
+    A.sorted = 0;
+    if (A.items && ((pk && pk[0] == 's') || (c->debug_flags & 2048)) && !noalloc && !(c->debug_flags & (2 | 4)) && p->max_depth <= 254 &&
+        (size_t)D.total_f4 * 16 + RT_SORT_WS_BYTES <= 64 * 1024) {
+        ItemPlan sp = plan_sorted(width, height, n_samples, c->n_cus);
+        if (c->debug_flags & 1024) sp.ok = true;
+        if (sp.ok) { A.sorted = 1; A.items = 0; A.unit_log2 = sp.unit_log2; A.n_groups = sp.n_groups; }
+    }
     int slices = 1;
     if (A.items) {
         ItemPlan ip = plan_items(width, height, n_samples, c->n_cus);
@@ -930,7 +952,7 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
         if (c->debug_flags & 1024) ip.ok = true;                 // tests: item form on small frames too
         A.items = ip.ok ? 1 : 0; A.unit_log2 = ip.unit_log2; A.n_groups = ip.n_groups;
     }
-    if (!A.items && n_samples > 0) slices = pick_slices(width, height, n_samples);
+    if (!A.items && !A.sorted && n_samples > 0) slices = pick_slices(width, height, n_samples);
     if (const char* e = getenv("RT_MI355_SLICES")) {      // experiment switch: sample slices per frame
         const int v = atoi(e);
         if (v >= 1 && v <= 64 && n_samples > 0) slices = v < n_samples ? v : n_samples;
@@ -941,7 +963,7 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     }
     A.slice_len = n_samples > 0 ? (n_samples + slices - 1) / slices : 1;
     slices = n_samples > 0 ? (n_samples + A.slice_len - 1) / A.slice_len : 1;
-    A.n_units = A.items ? A.n_groups * slices : 0;
+    A.n_units = (A.items || A.sorted) ? A.n_groups * slices : 0;
     float4* target = (float4*)d_accum;
     float4* partial = nullptr;
     if (slices > 1 && noalloc) partial = reinterpret_cast<float4*>(c->scratch_dev + RT_NOALLOC_SCENE_BYTES + RT_NOALLOC_COUNTER_BYTES);
@@ -954,11 +976,11 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     c->jit_note.clear();
     if (!noalloc && !accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && lds_fit &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
-        jit = jit_path_kernel(p->variant, H.slots, H.sruns, p->t_min, p->t_max, A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : RT_FORM_REGEN, c->jit_note);
+        jit = jit_path_kernel(p->variant, H.slots, H.sruns, p->t_min, p->t_max, A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : A.sorted ? RT_FORM_SORTED : RT_FORM_REGEN, c->jit_note);
     if (noalloc) c->jit_note = "allocation-free entry point: generic kernel";
     if ((rc = begin_timed(c, st, counters))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
     c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));
-    c->last_path_form = A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : RT_FORM_REGEN; c->last_unit_log2 = A.items ? A.unit_log2 : 0;
+    c->last_path_form = A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : A.sorted ? RT_FORM_SORTED : RT_FORM_REGEN; c->last_unit_log2 = (A.items || A.sorted) ? A.unit_log2 : 0;
     if (accel) { c->jit_note = "BVH walk (RT_OPT_ACCEL)"; launch_path_bvh(p->variant, D, A, target, slices, counters, st); }
     else launch_path(p->variant, D, A, target, slices, counters, st, jit, c->n_cus * 8);
     HIPCHK(c, hipGetLastError());
@@ -1236,7 +1258,7 @@ int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, i
     int rc = compile_scene(nullptr, scene, (variant & 7) == RT_JIT_WHITTED_SOFT ? 0 : (variant & 7), tmin, H);
     if (rc) return rc;
     std::string n;
-    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, tmin, 1000.0f, (variant & 8) ? RT_FORM_QUEUE : (variant & 16) ? RT_FORM_ITEMS : RT_FORM_REGEN, n);
+    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, tmin, 1000.0f, (variant & 8) ? RT_FORM_QUEUE : (variant & 16) ? RT_FORM_ITEMS : (variant & 32) ? RT_FORM_SORTED : RT_FORM_REGEN, n);
     if (note && cap > 0) { strncpy(note, n.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
     return fn ? 1 : 0;
 }

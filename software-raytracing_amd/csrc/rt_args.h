@@ -8,6 +8,11 @@
 #define RT_LDS_SCENE_MAX_BYTES (48 * 1024)
 #define RT_BVH_STACK 48   /* optional BVH walk: per-lane stack entries in LDS; the builder refuses deeper trees */
 
+// LDS workspace of the outcome-sorted form (path_sorted_body, rt_path_device.h) behind the staged scene blob
+#define RT_SORT_MAX_LOG2 7                                                  /* up to 128 pixels per workgroup unit */
+#define RT_SORT_XCH_BYTES (256 * 48)
+#define RT_SORT_WS_BYTES (2 * RT_SORT_XCH_BYTES + (1 << RT_SORT_MAX_LOG2) * (24 + 8) + 64)      /* 2 exchange buffers, sums, pixel table, counters */
+
 namespace rt {
 // Ray counters: one 64-bit atomic per wave and counter; 130k waves hitting ONE address cost ~3 ms at 4K (the whole 01
 // frame takes less), so the atomics are spread over banks (bank = block index mod RT_COUNTER_BANKS), summed on the host.
@@ -30,6 +35,7 @@ struct PathArgs {
     // item form (path_items_body): a unit of work = 2^unit_log2 consecutive pixels (row-major) x one sample slice; n_groups
     // pixel groups per slice, n_units = n_groups x slices units in all, handed out through counters[RT_WORK_COUNTER]
     int items, unit_log2, n_groups, n_units;
+    int sorted;                     // the outcome-sorted form (path_sorted_body): units belong to workgroups
     uint32_t seed;
     float t_min, t_min_pos, t_max;  // t_min_pos = max(t_min, smallest positive float): "t > 0 && t >= tMin" in one compare
     float inv_w2, inv_h2, kx, ky;   // 2/w, 2/h, tan(fov/2)*w/h, tan(fov/2)

@@ -160,7 +160,7 @@ __device__ __forceinline__ void rng_pair_raw(uint32_t skey, uint32_t ctr, float&
 //   [G | A | B | C | G1 G2 G3 S] rectangle, triangle                   (8 float4 = 128 bytes); S = bounding sphere (centre, R^2)
 // G..G3 feed the ray test, A,B,C feed shading and sit at the same offsets for every type, so the closest-hit
 // loop only has to remember WHERE the winner is (its byte offset in the blob), not what it is:
-//   A = (c.xyz, k)   B = (m.xyz, byte offset of the material record)   C = (f.xyz, 0)
+//   A = (c.xyz, k)   B = (m.xyz, byte offset of the material record)   C = (f.xyz, material class MAT_* as int bits)
 //   normal n = (p - c)*k/|p - c| + m, facing vector (p - c)*k/|p - c| + f; the hit is a back face when dot(d, facing) > 0.
 //     sphere: c = centre, k = +-1 ('inverted' negates), m = f = 0: Normalize(p - c)   (03 Sphere.hpp:57-73, 04 Scene/Sphere.hpp:58-74)
 //     planes, triangle: c = 0, k = 0, m = f = unit normal               (04 Scene/Plane.hpp:55-66)
@@ -396,6 +396,13 @@ __device__ __forceinline__ void key_take(uint32_t& ck, uint32_t& best, uint32_t 
     asm volatile("" ::"v"(diff));
     ck = further ? ck : k;
     best = further ? best : K;
+}
+
+// The same bookkeeping with a plain unsigned compare (generation 3 of the generated query): v_cmp_le_u32 + two selects.
+__device__ __forceinline__ void key_take3(uint32_t& ck, uint32_t& best, uint32_t k, uint32_t K) {
+    const bool take = k <= ck;
+    ck = take ? k : ck;
+    best = take ? K : best;
 }
 
 // wave64 sum of a per-lane counter, then one atomic per wave

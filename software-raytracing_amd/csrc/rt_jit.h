@@ -14,5 +14,6 @@ bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector
 hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note);
 // form: which body the kernel wraps - RT_FORM_REGEN path_body (per-lane regeneration), RT_FORM_QUEUE path_queue_body (workgroup-level
 // ray-queue compaction), RT_FORM_ITEMS path_items_body (persistent waves, work counter, lanes decoupled from pixels)
-enum { RT_FORM_REGEN = 0, RT_FORM_QUEUE = 1, RT_FORM_ITEMS = 2 };
+// RT_FORM_SORTED path_sorted_body (the workgroup sorts its paths by the outcome of the scene query)
+enum { RT_FORM_REGEN = 0, RT_FORM_QUEUE = 1, RT_FORM_ITEMS = 2, RT_FORM_SORTED = 3 };
 }

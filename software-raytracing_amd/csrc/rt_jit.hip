@@ -208,14 +208,14 @@ bool sphere_interior_is_empty(const std::vector<float4>& slots, const std::vecto
     return true;
 }
 
-std::string gen_closest_hit_v2(const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax) {
+std::string gen_closest_hit_v2(const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, bool plain_compare) {
     const float tminp = tmin > 0.0f ? tmin : 1.401298464e-45f;
     Jit2 J{fbits(tminp), fbits(tmax) - fbits(tminp), 0x7f800000U - fbits(tminp)};
     const std::string C = hex(J.C);
     std::string s;
     s += "namespace rt {\n__device__ __forceinline__ uint32_t closest_hit_jit(f3 o, f3 d, float, float, float, float& t_out) {\n";
     s += "    uint32_t best = 0U, ck = " + hex(J.ck0) + ";\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d;\n";
-    auto take = [](const std::string& K) { return " key_take(ck, best, k, " + K + "); }\n"; };
+    auto take = [&](const std::string& K) { return std::string(plain_compare ? " key_take3" : " key_take") + "(ck, best, k, " + K + "); }\n"; };
     size_t q = 0;
     const char* skip = getenv("RT_MI355_JIT_SKIP");      // timing experiments only: leave a primitive type out of the generated query (wrong images)
     for (const int4& run : sruns) {
@@ -306,8 +306,8 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     const char* gen_env = getenv("RT_MI355_JIT_GEN");
     bool has_strict = false;      // slots in the reference's operation sequence (rt_device.h PRIM_*_STRICT): generation 1 only
     for (const int4& r : sruns) has_strict = has_strict || is_strict_type(r.x);
-    const bool gen2 = variant != RT_JIT_WHITTED_SOFT && gen_env && gen_env[0] == '2' && tmin >= 0.0f && tmax > tmin && std::isfinite(tmax) && !has_strict;
-    src += (gen2 ? gen_closest_hit_v2(slots, sruns, tmin, tmax) : gen_closest_hit(slots, sruns)) + gen_any_hit(slots, sruns);
+    const bool gen2 = variant != RT_JIT_WHITTED_SOFT && gen_env && (gen_env[0] == '2' || gen_env[0] == '3') && tmin >= 0.0f && tmax > tmin && std::isfinite(tmax) && !has_strict;
+    src += (gen2 ? gen_closest_hit_v2(slots, sruns, tmin, tmax, gen_env[0] == '3') : gen_closest_hit(slots, sruns)) + gen_any_hit(slots, sruns);
     const char* entry = variant == RT_JIT_WHITTED_SOFT ? "k_whitted_jit" : "k_path_jit";
     if (variant == RT_JIT_WHITTED_SOFT)   // 02: the generated query serves the shadow samples of whitted_body<true>
         src += std::string(kSrcStrict) + "\n" + kSrcWhitted +
@@ -316,7 +316,7 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     else
         src += std::string(kSrcPath) +
             "\nextern \"C\" __global__ __launch_bounds__(256) void k_path_jit(rt::DevScene SD, rt::PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
-            "    rt::path_" + std::string(form == RT_FORM_QUEUE ? "queue_" : form == RT_FORM_ITEMS ? "items_" : "") + "body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
+            "    rt::path_" + std::string(form == RT_FORM_QUEUE ? "queue_" : form == RT_FORM_ITEMS ? "items_" : form == RT_FORM_SORTED ? "sorted_" : "") + "body<" + std::to_string(variant) + ", true>(SD, A, out, counters);\n}\n";
     int dev = 0; (void)hipGetDevice(&dev);
     const auto key = std::make_pair(dev, fnv1a(src));
     std::lock_guard<std::mutex> lock(g_mu);

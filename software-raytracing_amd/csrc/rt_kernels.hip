@@ -35,6 +35,12 @@ __global__ __launch_bounds__(256) void k_path_items(DevScene SD, PathArgs A, flo
     path_items_body<VARIANT, LDS, EARLY>(SD, A, out, counters);
 }
 
+// Outcome-sorted form (rt_path_device.h): workgroups pull units, sort their paths by the query's outcome through LDS.
+template <int VARIANT, bool LDS, bool EARLY = false>
+__global__ __launch_bounds__(256) void k_path_sorted(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    path_sorted_body<VARIANT, LDS, EARLY>(SD, A, out, counters);
+}
+
 template <int VARIANT>
 static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int n_slices, unsigned long long* counters, hipStream_t st, hipFunction_t jit, int items_grid_blocks) {
     dim3 grid(((A.width + 15) / 16) * ((A.height + 15) / 16), n_slices);
@@ -43,11 +49,18 @@ static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int
     // item form: a persistent grid - as many blocks as the chip holds (the host's estimate; more would only find the counter exhausted), at most one wave per unit
     const bool items = A.items && !queue;
     if (items) grid = dim3((unsigned)std::max(1, std::min(items_grid_blocks, (A.n_units + 3) / 4)), 1);
+    const bool sorted = A.sorted && !queue && !items;
+    if (sorted) grid = dim3((unsigned)std::max(1, std::min(items_grid_blocks, A.n_units)), 1);
     if (jit && bytes <= RT_LDS_SCENE_MAX_BYTES) {   // scene-specialised k_path<VARIANT, true> / k_path_items / k_path_q (rt_jit.hip)
         DevScene s = S; PathArgs a = A;
         void* params[] = {&s, &a, &out, &counters};
-        if (hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)(bytes + (queue ? RT_Q_WS_BYTES : 0) + (items ? 4 * RT_ITEMS_WAVE_BYTES : 0)), st, params, nullptr) == hipSuccess) return;
+        if (hipModuleLaunchKernel(jit, grid.x, grid.y, 1, 256, 1, 1, (unsigned)(bytes + (queue ? RT_Q_WS_BYTES : 0) + (items ? 4 * RT_ITEMS_WAVE_BYTES : 0) + (sorted ? RT_SORT_WS_BYTES : 0)), st, params, nullptr) == hipSuccess) return;
         (void)hipGetLastError();   // could not launch the specialised kernel: the generic one below renders the same image
+    }
+    if (sorted) {
+        if (S.slot_bytes > 64 * 64) hipLaunchKernelGGL((k_path_sorted<VARIANT, true, true>), grid, dim3(256), bytes + RT_SORT_WS_BYTES, st, S, A, out, counters);
+        else                        hipLaunchKernelGGL((k_path_sorted<VARIANT, true>), grid, dim3(256), bytes + RT_SORT_WS_BYTES, st, S, A, out, counters);
+        return;
     }
     if (items) {
         const size_t ws = 4 * RT_ITEMS_WAVE_BYTES;

@@ -521,6 +521,175 @@ __device__ __forceinline__ void path_queue_body(const DevScene& SD, const PathAr
     wave_add_u64(counters + 2 * ((blockIdx.x + blockIdx.y) % RT_COUNTER_BANKS), L.rays);
 }
 
+// =================================================================================================
+// Outcome-sorted form of the bounce loop (K3/K4): the workgroup sorts its 256 paths by what the scene
+// query found, so that every wave runs ONE kind of work.
+//
+// On 03 a ray leaves to the sky 46 % of the time: in path_body / path_items_body each wave then runs the shading code with
+// ~54 % of its lanes and the camera code with ~46 % (measured lane utilisation 0.70).  Here, after the query,
+//   * a path that ENDS (miss: the sky term; a light; no material; the depth limit) hands its radiance to the pixel's fixed-point
+//     sum in LDS at once and frees its lane - nothing of it is exchanged;
+//   * a path that SCATTERS writes its 48-byte state (origin, direction, throughput, RNG key, depth | pixel | hit slot, t) to an
+//     LDS exchange buffer, diffuse / metal hits from the front (rank = wave base from one LDS atomic + mbcnt of the ballot),
+//     dielectric hits from the back;
+// and after ONE barrier (the buffer and its counters are double / triple buffered) thread i < nA reads state i and shades it,
+// the last nB threads shade the dielectric hits, and every thread in between starts a new path from the unit's next items - so
+// shading, refraction and camera code each run in full waves (one boundary wave per class apart).  The workgroup pulls units
+// of work (pixel group x sample range) from the global work counter like path_items_body's waves do; sums are the same 32.32
+// fixed point, so the frame is bit-identical to the item form's (same paths, order-independent sums).
+// =================================================================================================
+template <int VARIANT, bool LDS, bool EARLY = false>
+__device__ __forceinline__ void path_sorted_body(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    extern __shared__ float4 smem[];
+    const char* base = reinterpret_cast<const char*>(SD.blob);
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t ws_off = 0U;
+    if (LDS) {
+        for (int i = tid; i < SD.total_f4; i += 256) smem[i] = SD.blob[i];
+        base = reinterpret_cast<const char*>(smem);
+        ws_off = (uint32_t)SD.total_f4 * 16U;
+    }
+    char* const ws = reinterpret_cast<char*>(smem) + ws_off;
+    float4* const xch = reinterpret_cast<float4*>(ws);                                                   // [2][256][3]
+    unsigned long long* const acc = reinterpret_cast<unsigned long long*>(ws + 2 * RT_SORT_XCH_BYTES);   // [pixel][rgb]
+    uint2* const pixtab = reinterpret_cast<uint2*>(ws + 2 * RT_SORT_XCH_BYTES + (1 << RT_SORT_MAX_LOG2) * 24);
+    uint32_t* const cnt = reinterpret_cast<uint32_t*>(ws + 2 * RT_SORT_XCH_BYTES + (1 << RT_SORT_MAX_LOG2) * 32);   // [3 sets][2] + [6] unit word
+    const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
+    const SceneMem<LDS> M{base};
+    const uint32_t slots0 = M.at((uint32_t)SD.off_slots * 16U), mats0 = M.at(0U);
+    const int k = A.unit_log2, P = 1 << k;
+    const uint32_t n_pixels = (uint32_t)A.width * (uint32_t)A.height;
+    unsigned int rays = 0;
+
+    for (;;) {
+        __syncthreads();                       // the previous unit's sums are stored (and, first time round, the blob is staged)
+        if (tid == 0) cnt[6] = (uint32_t)atomicAdd(counters + RT_WORK_COUNTER, 1ULL);
+        if (tid < 6) cnt[tid] = 0U;
+        __syncthreads();
+        const uint32_t u = cnt[6];
+        if (u >= (uint32_t)A.n_units) break;
+        uint32_t slice = 0U, group = u;
+        if (A.n_units != A.n_groups) { slice = u / (uint32_t)A.n_groups; group = u - slice * (uint32_t)A.n_groups; }
+        const int s_first = A.sample_begin + (int)slice * A.slice_len;
+        const int s_end = min(s_first + A.slice_len, A.sample_end);
+        const uint32_t first_px = group << k;
+        const uint32_t by = first_px / (uint32_t)A.width, bx = first_px - by * (uint32_t)A.width;
+        const uint32_t n_items = (uint32_t)max(s_end - s_first, 0) << k;
+        uint32_t my_pixel = 0xFFFFFFFFU;
+        if (tid < P) {
+            uint32_t x = bx + (uint32_t)tid, y = by;
+            while (x >= (uint32_t)A.width) { x -= (uint32_t)A.width; ++y; }
+            const uint32_t pixel = y * (uint32_t)A.width + x;
+            const bool inside = pixel < n_pixels;
+            if (inside) my_pixel = pixel;
+            pixtab[tid] = make_uint2(rng_pixel_key(A.seed, pixel), inside ? (x | (y << 16)) : 0xFFFFFFFFU);
+            acc[3 * tid] = 0ULL; acc[3 * tid + 1] = 0ULL; acc[3 * tid + 2] = 0ULL;
+        }
+        PathLane L = lane_init(0);
+        L.acc0 = (uint32_t)(uintptr_t)(RT_LDS_AS char*)acc;
+        uint32_t item_base = 0U;
+        int set = 0, buf = 0;
+        uint32_t hit = 0U; float t = 0.0f;
+        // (the first barrier of the bounce loop also publishes the table and the zeroed sums)
+
+        for (;;) {
+            // ---- scene query of every live path; paths that end are settled here, scattering paths are written out sorted
+            bool hit_a = false, hit_b = false;
+            if (L.alive) {
+                ++rays;
+#ifdef RT_JIT_SCENE
+                const uint32_t kk = closest_hit_jit(L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+                hit = kk + (slots0 - SLOT_BYTES);
+                const bool miss = kk == 0U;
+                (void)runs;
+#else
+                hit = closest_hit_slots<LDS, EARLY>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+                const bool miss = hit == 0U;
+#endif
+                if (miss) {
+                    if (VARIANT == 3) {   // sky (03 Main.cpp:430-432), as in shade()
+                        float h = 0.5f * (L.d.y + 1.0f);
+                        add_radiance<true>(L, L.thr * F3(fmaf(-0.5f, h, 1.0f), fmaf(-0.3f, h, 1.0f), 1.0f));
+                    }
+                } else {
+                    const int mtype = __float_as_int(M.ld1(hit + SLOT_C + 12U));      // the slot's material class (compile_scene)
+                    const bool scatters = (mtype == MAT_DIFFUSE) | (mtype == MAT_METAL) | (mtype == MAT_DIELECTRIC);
+                    if (scatters & (L.depth < A.max_depth)) { hit_a = mtype != MAT_DIELECTRIC; hit_b = !hit_a; }
+                    else if (VARIANT == 4 && mtype == MAT_LIGHT) {   // emits from its front face (Light.hpp:47-54) at any depth and ends the path; the hit record as in shade(), bit for bit
+                        const float4 sa = M.ld4(hit + SLOT_A), sb = M.ld4(hit + SLOT_B), sc = M.ld4(hit + SLOT_C);
+                        const f3 pc = madd(L.d, t, L.o) - F3(sa);
+                        const float kq = sa.w * rsq_fast(fmaf(pc.z, pc.z, fmaf(pc.y, pc.y, fmaf(pc.x, pc.x, 1e-30f))));
+                        if (!(dot(L.d, madd(pc, kq, F3(sc))) > 0.0f)) add_radiance<true>(L, L.thr * F3(M.ld4(mats0 + __float_as_uint(sb.w))));
+                    }
+                    // else: no material, or a bounce whose continuation the depth limit would cut (03 Main.cpp:383-386, 04 Main.cpp:438-441): the path ends black
+                }
+                L.alive = false;
+            }
+            const unsigned long long m_a = __builtin_amdgcn_ballot_w64(hit_a), m_b = __builtin_amdgcn_ballot_w64(hit_b);
+            uint32_t b_a = 0U, b_b = 0U;
+            if (lane == 0) {
+                if (m_a) b_a = atomicAdd(&cnt[2 * set], (uint32_t)__popcll(m_a));
+                if (m_b) b_b = atomicAdd(&cnt[2 * set + 1], (uint32_t)__popcll(m_b));
+            }
+            b_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_a); b_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_b);
+            if (hit_a | hit_b) {
+                const unsigned long long m = hit_a ? m_a : m_b;
+                const uint32_t r = (hit_a ? b_a : b_b) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0U));
+                float4* dst = xch + (size_t)buf * 768 + 3U * (hit_a ? r : 255U - r);
+                dst[0] = make_float4(L.o.x, L.o.y, L.o.z, L.d.x);
+                dst[1] = make_float4(L.d.y, L.d.z, L.thr.x, L.thr.y);
+                dst[2] = make_float4(L.thr.z, __uint_as_float(L.rkey), __uint_as_float((uint32_t)L.depth | (L.pl << 8) | ((hit - slots0) << 10)), t);   // slot offsets are multiples of 64: 6 spare bits
+            }
+            __syncthreads();                   // states and counters of this bounce are complete; the other buffer / the third counter set are free
+            const uint32_t n_a = cnt[2 * set], n_b = cnt[2 * set + 1];
+            { const int s2 = set == 0 ? 2 : set - 1; if (tid < 2) cnt[2 * s2 + tid] = 0U; }      // the set of the bounce before this one: everybody read it before this barrier
+            if (n_a + n_b == 0U && item_base >= n_items) break;      // workgroup-uniform: nothing in flight, nothing left to start
+            const bool take_a = (uint32_t)tid < n_a, take_b = (uint32_t)tid >= 256U - n_b;
+            if (take_a | take_b) {
+                const float4* src = xch + (size_t)buf * 768 + 3U * (uint32_t)tid;
+                const float4 a = src[0], b = src[1], c = src[2];
+                L.o = F3(a.x, a.y, a.z); L.d = F3(a.w, b.x, b.y); L.thr = F3(b.z, b.w, c.x);
+                L.rkey = __float_as_uint(c.y);
+                const uint32_t meta = __float_as_uint(c.z);
+                L.depth = (int)(meta & 0xFFU); L.pl = (meta >> 8) & 0x7FU; hit = (meta >> 16 << 6) + slots0;
+                L.alive = true;
+                shade<VARIANT, LDS, true>(M, A, mats0, false, hit, c.w, L);
+            } else {
+                const uint32_t item = item_base + ((uint32_t)tid - n_a);
+                if (item < n_items) {
+                    L.pl = item & (uint32_t)(P - 1);
+                    const uint2 pt = pixtab[L.pl];
+                    if (pt.y != 0xFFFFFFFFU) {  // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369); same arithmetic as regenerate()
+                        const uint32_t x = pt.y & 0xFFFFU, y = pt.y >> 16;
+                        L.skey = rng_sample_key(pt.x, (uint32_t)s_first + (item >> k));
+                        L.rkey = L.skey + 5U * 0x9E3779B9U;
+                        float bxj = 0.5f, byj = 0.5f;
+                        if (A.jitter) rng_pair(L.skey, 0U, bxj, byj);
+                        float cx = fmaf((float)(int)x + bxj, A.inv_w2, -1.0f) * A.kx;
+                        float cy = -fmaf((float)(int)y + byj, A.inv_h2, -1.0f) * A.ky;
+                        f3 v = F3(cx, cy, -1.0f);
+                        const f3 rv = F3(dot(F3(A.r[0], A.r[1], A.r[2]), v), dot(F3(A.r[3], A.r[4], A.r[5]), v), dot(F3(A.r[6], A.r[7], A.r[8]), v));
+                        L.d = rv * rsq_fast(dot(rv, rv));
+                        L.o = F3(A.px, A.py, A.pz);
+                        L.thr = F3(1, 1, 1);
+                        L.depth = 0;
+                        L.alive = true;
+                    }
+                }
+            }
+            item_base += 256U - (n_a + n_b);
+            set = set == 2 ? 0 : set + 1; buf ^= 1;
+        }
+        __syncthreads();                       // every deposit of the unit has landed
+        if (my_pixel != 0xFFFFFFFFU) {
+            const unsigned long long r = acc[3 * tid], g = acc[3 * tid + 1], b = acc[3 * tid + 2];
+            auto tof = [](unsigned long long v) { return (float)((double)v * (1.0 / 4294967296.0)); };
+            out[(size_t)slice * n_pixels + my_pixel] = make_float4(tof(r), tof(g), tof(b), (float)max(s_end - s_first, 0));
+        }
+    }
+    wave_add_u64(counters + 2 * ((blockIdx.x * 4 + (tid >> 6)) % RT_COUNTER_BANKS), rays);
+}
+
 // Large scenes (blob > 48 KB): the slot section is walked in pieces of <= RT_TILE_BYTES that the block's four waves
 // stage through LDS together (one global read per block instead of one per wave, and VGPR operands for the tests), so
 // the bounce loop runs in lockstep per BLOCK: regenerate per wave, then every chunk between two barriers, then shade.

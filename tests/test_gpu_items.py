@@ -126,3 +126,22 @@ def test_colours_outside_the_fixed_point_range_keep_float_sums(ctx):
     s.materials[1].albedo[0] = 1.5; s._c = None
     r = _render(ctx, 1024, s, cam, prm, 98, 70)
     assert r["form"][0] == 0 and np.isfinite(r["rgb"]).all()
+
+
+@pytest.mark.parametrize("name", ["04", "03", "03 readme", "04 odd size", "nest"])
+@pytest.mark.parametrize("kernel", ["generic", "specialised"])
+def test_outcome_sorted_form_renders_the_item_form_frame_bit_for_bit(ctx, name, kernel):
+    """path_sorted_body (debug flag 2048 / RT_MI355_PATH=s: the workgroup sorts its paths by what the query found, settles ended
+    paths before the exchange, shades scattering ones in full waves) traces the same paths and adds into the same fixed-point
+    sums as the item form: identical ray counts, identical frames.  It lost its A/B on the GPU (profiles/r03_pmc_forms.txt)."""
+    (s, cam, prm), (w, h) = _cases()[name]
+    extra = {"generic": 8, "specialised": 16}[kernel]
+    a = _render(ctx, extra | 1024 | 2048, s, cam, prm, w, h)
+    b = _render(ctx, extra | 1024, s, cam, prm, w, h)
+    assert a["form"][0] == 3 and b["form"][0] == 2
+    assert a["rays"] == b["rays"] and np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["bgra"], b["bgra"])
+    # a depth limit that cuts paths short: the sorted form settles "would be cut" before the exchange
+    prm2 = scenes.path_params(prm.variant, prm.spp, max_depth=2, seed=7)
+    a = _render(ctx, extra | 1024 | 2048, s, cam, prm2, w, h)
+    b = _render(ctx, extra | 1024, s, cam, prm2, w, h)
+    assert a["rays"] == b["rays"] and np.array_equal(a["rgb"], b["rgb"])

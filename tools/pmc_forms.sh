@@ -1,0 +1,11 @@
+#!/bin/bash
+# GPU box: PMC pass per form of the bounce loop on 03 (1080p / 256 spp) and 04 (4K / 256 spp): tools/pmc_forms.sh -> gpurun_out/pmc_forms/
+# forms: 0 item form (default), 512 one lane per pixel (per-lane regeneration), 2048 outcome-sorted, 256 queue
+set -o pipefail
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_forms; rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for which in 03 04; do for f in 0 512 2048 256; do
+  D=$OUT/${which}_$f; mkdir -p $D
+  timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $D -o p -- python3 $R/tools/sorted_ab.py time$which $f > $D/run.log 2>&1 || exit 1
+  echo "== $which form-flag $f"; tail -1 $D/run.log; python3 $R/tools/pmc_summary.py $(dirname $(find $D -name "*counter_collection.csv" | head -1))
+done; done 2>&1 | tee $OUT/summary.txt
