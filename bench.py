@@ -6,7 +6,8 @@ A step = one full render of BASELINE.json config 4: the 04 scene at 3840x2160, 1
 8-bit BGRA frame in HBM.  With N ranks (one process per GPU, torch.distributed/RCCL) the frame's
 samples are split into N contiguous ranges - rank r renders samples [r*spp/N, (r+1)*spp/N) of every
 pixel - and the per-GPU float accumulators (3840*2160*4 floats = 132.7 MB) are combined with ONE
-all-reduce over xGMI before the resolve; total work is fixed, so scaling is "strong".
+all-reduce over xGMI before the resolve (the three data floats of every pixel, packed: 99.5 MB); total work is fixed, so scaling is "strong".
+N > 1 runs add per-rank ray counts and the stream-side phases of a step (render / pack / all-reduce / unpack + resolve, HIP events) to `config`.
 
 Prints ONE JSON line (rank 0).  roofline: FP32 VALU (no MFMA on this path), algorithmic FLOPs per ray
 from SURVEY.md 8(d) (04 scene: 249) x rays the kernel counted / the kernel's HIP-event duration.
@@ -114,10 +115,14 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not rehearsal and torch.cuda.device_count() < world:      # fail loudly, never fold ranks onto fewer devices
+            raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} GPU(s) to rank {rank}")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}")
 
     W, H, SPP = args.width, args.height, args.spp
     ctx = lib.Context(local)
@@ -133,25 +138,36 @@ def main():
     assert sp != 0
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
     bgra = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    # the collective carries the three data floats of a pixel, packed (99.5 MB at 4K), not the float4 accumulator (132.7 MB)
+    rgb = torch.zeros(H * W, 3, dtype=torch.float32, device="cuda") if world > 1 else None
     torch.cuda.synchronize()
     empty_share = shard.is_empty((s_begin, s_end))
+    # Host wait between render and collective: only in the one-GPU rehearsal (BENCH_HOST_SYNC=1 forces it, =0 removes it).
+    # A real run orders render -> all-reduce -> resolve on ONE stream and never blocks the host inside a step.
+    host_sync = os.environ.get("BENCH_HOST_SYNC", "1" if rehearsal else "0") == "1"
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]      # render begin / end, all-reduce begin / end, resolve end - all on `stream`
 
     def step():
         with torch.cuda.stream(stream):
+            ev[0].record(stream)
             if empty_share:
                 accum.zero_()                                        # spp < world: this rank adds nothing
             else:
                 ctx.path_accumulate_device(s, cam, prm, W, H, accum.data_ptr(), sp)
+            ev[1].record(stream)
             if world > 1:
-                # The host waits for this rank's render before the collective is issued (it reads the ray counter here anyway;
-                # the cost is one launch latency per frame).  Found by the rehearsal: with two processes on ONE GPU, gloo's CUDA
-                # all-reduce (event wait on a side stream + pinned staging from a worker thread) never returned while both
-                # processes' render kernels were still pending; with the host wait it does.  tools/xstream_probe.py shows the
-                # same cross-stream wait on a pending kernel works within one process, so RCCL on one GPU per process is not
-                # expected to need this - but an N-GPU job that hangs loses the whole measurement, and the wait is free.
-                ctx.sync(sp)
-                dist.all_reduce(accum, op=dist.ReduceOp.SUM)          # the one collective: per-GPU spp accumulators
+                if host_sync:
+                    ctx.sync(sp)
+                a4 = accum.view(H * W, 4)
+                rgb.copy_(a4[:, :3])
+                ev[2].record(stream)
+                dist.all_reduce(rgb, op=dist.ReduceOp.SUM)            # the one collective: per-GPU sums of the sample shares
+                ev[3].record(stream)
+                a4[:, :3].copy_(rgb)
+            else:
+                ev[2].record(stream); ev[3].record(stream)
             ctx.resolve_device(accum.data_ptr(), W, H, float(SPP), 1, bgra.data_ptr(), 0, None, sp)
+            ev[4].record(stream)
 
     def fence():
         if world > 1:
@@ -170,12 +186,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms, rays = [], 0
+    kernel_ms, rays, phases = [], 0, []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         st = ctx.sync(sp)          # waits for this step (also collects the kernel's ray counter and HIP-event time)
         kernel_ms.append(st["kernel_ms"]); rays = st["rays"]
+        # stream-side phases of the step (HIP events on the step's stream): render, gap + pack before the collective, the collective, unpack + resolve
+        phases.append([ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), ev[3].elapsed_time(ev[4])])
     fence()
     dt = time.perf_counter() - t0
 
@@ -185,6 +203,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
     dt = float(t.item()); rays_step = float(r.item())
+    ph = torch.tensor(np.mean(phases, axis=0), dtype=torch.float64, device="cuda")
+    per_rank = torch.tensor([float(rays), float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        gathered = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(gathered, per_rank)
+        ph_max = ph.clone(); dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
+    else:
+        gathered, ph_max = [per_rank], ph
 
     if rehearsal and world > 1 and rank == 0:
         # the composed frame (N sample-range shards + all-reduce + resolve) against the same frame rendered by one context alone
@@ -198,6 +224,9 @@ def main():
         print(f"rehearsal: composed {world}-rank frame == single-context frame (max byte diff {int(diff.max())}, {float((diff > 0).float().mean()):.2e} of bytes differ)", file=sys.stderr)
 
     if rank == 0:
+        form, unit_log2 = ctx.last_path_form()
+        body = {0: "rt::path_body (one lane per pixel)", 1: "rt::path_queue_body", 2: f"rt::path_items_body (persistent waves, work counter, {1 << unit_log2} pixels per unit)", 3: "rt::path_sorted_body"}.get(form, "?")
+        kernel_name = {2: f"k_path_jit (scene-specialised {body}<4, true>, hiprtc)", 1: f"generic {body}<4, true>", 0: "rt::k_path_tiled<4>"}.get(ctx.last_path_kernel()[0], "?")
         fpr = scenes.flops_per_ray(s, 100)                           # 17*3 + 12*5 + 38 + 100 = 249
         k_ms = float(np.mean(kernel_ms))                             # rank 0's tracing kernel (+slice sum), HIP events on its stream
         achieved = rays * fpr / (k_ms * 1e-3) / 1e12
@@ -205,7 +234,7 @@ def main():
         # this very command under --pmc FETCH_SIZE and --pmc WRITE_SIZE); the committed summary of those passes is quoted,
         # with its source, when it is for this workload - else null
         traffic = None
-        pj = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+        pj = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
         if world == 1 and os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
@@ -220,9 +249,14 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"04_PathTracingLights scene (5 planes, 3 spheres, 1 emissive rectangle), {W}x{H}, {SPP} spp, max depth 6, seed 1",
                        "jit_compiler": jit_compiler, "samples_per_step": W * H * SPP, "rays_per_step": rays_step, "samples_per_sec": W * H * SPP * args.steps / dt,
-                       "parallelism": (f"sample-range x{world}, one all-reduce(sum) of the {W * H * 16 / 1e6:.1f} MB accumulator" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")) if world > 1 else "single GPU"},
+                       "parallelism": (f"sample-range x{world}, one all-reduce(sum) of the packed RGB sums ({W * H * 12 / 1e6:.1f} MB)" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")) if world > 1 else "single GPU",
+                       "rays_per_rank": [int(g[0].item()) for g in gathered], "kernel_ms_per_rank": [round(float(g[1].item()), 3) for g in gathered],
+                       "phase_ms_rank0": {"render": round(float(ph[0]), 3), "pack": round(float(ph[1]), 3), "allreduce": round(float(ph[2]), 3), "unpack_resolve": round(float(ph[3]), 3)},
+                       "phase_ms_max_over_ranks": {"render": round(float(ph_max[0]), 3), "pack": round(float(ph_max[1]), 3), "allreduce": round(float(ph_max[2]), 3), "unpack_resolve": round(float(ph_max[3]), 3)},
+                       "host_sync_before_collective": bool(host_sync and world > 1)},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": traffic, "traffic_source": ("profiles/r02_pmc_hbm_traffic.json: separate rocprofv3 --pmc passes of this command, not this run; 8 partial images (sample slices, DESIGN.md 5) on purpose: algorithmic bytes are 16 B/pixel = 132.7 MB" if traffic is not None else None), "kernel": {2: "k_path_jit (scene-specialised rt::path_body<4, true>, hiprtc; kernel_ms includes k_sum_slices, 0.2 ms)", 1: "rt::k_path<4, true>", 0: "rt::k_path_tiled<4>"}.get(ctx.last_path_kernel()[0], "?"), "kernel_ms": k_ms, "kernel_ms_steps": [round(x, 3) for x in kernel_ms], "flops_per_ray": fpr, "rays_per_launch": rays,
+                         "traffic": traffic, "traffic_source": ("profiles/r03_pmc_hbm_traffic.json: separate rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE), not this run; algorithmic bytes are 16 B/pixel = 132.7 MB" if traffic is not None else None),
+                         "kernel": kernel_name, "kernel_ms": k_ms, "kernel_ms_steps": [round(x, 3) for x in kernel_ms], "flops_per_ray": fpr, "rays_per_launch": rays,
                          "note": "FP32 VALU-bound path (no MFMA, negligible HBM traffic): algorithmic FLOPs/ray x rays / kernel time vs the FP32 vector peak"},
         }
         if world == 1 and not args.no_cpu_baseline:

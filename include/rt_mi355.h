@@ -174,9 +174,14 @@ rt_ctx* rt_create(int32_t device_id);
  * device_ids[i] renders range i of EVERY pixel into its own accumulator (all devices side by side, one stream each), the
  * accumulators are combined with ONE RCCL all-reduce(sum, float32) over xGMI (librccl is loaded at this call, with
  * dlopen), and device_ids[0] resolves the frame.  The result does not depend on n_devices except for the order of the
- * float additions.  A device id may be listed more than once (rehearsal of the group code on one GPU; the sums then go
- * through copies to device_ids[0] instead of RCCL).  Whitted renders and the device-buffer entry points use
- * device_ids[0] only.  Returns NULL on failure (rt_last_error(NULL)); rt_destroy frees the whole group. */
+ * float additions.  A device id may be listed more than once (rehearsal of the group code on one GPU), RCCL may be
+ * missing or fail to initialise, RT_MI355_NO_RCCL may be set: the sums then go through copies to device_ids[0], added in a
+ * fixed order (root-gather form) - never an error.  Whitted renders and the device-buffer entry points use device_ids[0]
+ * only.  Returns NULL on failure (null list, count outside [1, 64], a device that rt_create refuses; rt_last_error(NULL));
+ * rt_destroy frees the whole group.
+ * STATE OF VERIFICATION: the fan-out, the root-gather sum and the resolve are tested on hardware (a group that lists one GPU
+ * twice); RCCL's run-time binding is tested with a one-rank communicator.  The all-reduce across DISTINCT devices has never
+ * run on hardware (no multi-GPU node was available to any round): parity of that path is unpinned. */
 rt_ctx* rt_create_multi(const int32_t* device_ids, int32_t n_devices);
 void    rt_destroy(rt_ctx* ctx);
 const char* rt_last_error(const rt_ctx* ctx);   /* ctx may be NULL for rt_create failures    */
@@ -240,8 +245,9 @@ int32_t rt_progressive_end(rt_ctx* ctx);
 int32_t rt_path_accumulate_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* camera,
                                   const rt_path_params* params, int32_t width, int32_t height,
                                   float* d_accum, void* stream);
-/* rt_path_accumulate_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same result as
+/* rt_path_accumulate_device for callers that may not allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc).  Not capturable into a HIP graph: it waits on an event and records timing events on the stream.
+ * No counterpart in the reference.  Same arguments, same result as
  * rt_path_accumulate_device, but everything the kernels need beyond the caller's buffers - the flattened scene, the ray
  * counters and the per-slice partial sums - lives in ONE fixed array that is part of the library's code object (a
  * static __device__ array; every GPU the library runs on holds its own copy from module load to process end), and this
@@ -250,8 +256,10 @@ int32_t rt_path_accumulate_device(rt_ctx* ctx, const rt_scene* scene, const rt_c
  * rectangles/triangles; larger -> RT_ERR_TOO_LARGE); the partial sums use at most partial_bytes (32 MiB): an image too large
  * for several slices is rendered with fewer, or written straight into d_accum - any width*height the other entry point takes.
  * RT_OPT_ACCEL must be RT_ACCEL_NONE (else RT_ERR_UNSUPPORTED).
- * All calls on one GPU - from any context, any stream - share that GPU's array, which keeps the last call's contents:
- * calls that overlap in time on one GPU race; finish one (rt_sync) before the next starts. */
+ * All calls on one GPU - from any context, any stream - share that GPU's array, which keeps the last call's contents.  A
+ * call first waits (on the host) for the previous call's kernels on that GPU, whichever context and stream issued them (one
+ * guard event per GPU), so consecutive calls are safe; two host threads ENTERING the call for one GPU at the same time still
+ * race: one at a time per GPU. */
 int32_t rt_path_accumulate_device_noalloc(rt_ctx* ctx, const rt_scene* scene, const rt_camera* camera,
                                           const rt_path_params* params, int32_t width, int32_t height,
                                           float* d_accum, void* stream);

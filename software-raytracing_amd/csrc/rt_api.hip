@@ -16,6 +16,7 @@
 #include "rt_kernels.h"
 #include "rt_jit.h"
 #include "rt_bvh.h"
+#include "../../include/rt_mi355_debug.h"
 
 using namespace rt;
 
@@ -33,6 +34,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES]
 namespace {
 constexpr int RT_MAX_DEVICES = 64;
 unsigned char* g_scratch_ptr[RT_MAX_DEVICES] = {};       // device address of 'scratch' per HIP device, filled by rt_create
+hipEvent_t g_scratch_ev[RT_MAX_DEVICES] = {};            // per device, like the array it guards: recorded behind the last kernel that used this GPU's scratch, by whichever context and stream
 std::mutex g_scratch_mu;
 
 thread_local std::string g_create_error;
@@ -128,7 +130,7 @@ struct rt_ctx {
     hipEvent_t ev_scene_use = nullptr;            // recorded behind the last work that reads scene_buf / h_stage, on whichever stream it ran
     // allocation-free entry point: this device's copy of 'scratch', a fixed pinned staging buffer for its scene blob (both
     // set up once by rt_create) and the event behind the last kernel that read them
-    unsigned char* scratch_dev = nullptr; void* h_stage_na = nullptr; hipEvent_t ev_scene_use_na = nullptr;
+    unsigned char* scratch_dev = nullptr; void* h_stage_na = nullptr; hipEvent_t ev_scene_use_na = nullptr;      // the event is the DEVICE's (g_scratch_ev), not owned
     bool timing_pending = false;
     DevBuf scene_buf, partial, accum, bgra, rgb;
     unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
@@ -149,6 +151,7 @@ struct rt_ctx {
     std::vector<hipEvent_t> peer_done;            // per peer, on its device: its accumulator is complete
     hipEvent_t ar0 = nullptr, ar1 = nullptr;      // timing of the sum on this device's stream
     void* rccl_lib = nullptr; std::vector<void*> comms;   // RCCL communicators, one per device of the group (all devices distinct)
+    std::string group_note;                       // how the group sums its accumulators, and why (rt_debug_group_mode)
     DevBuf gather;                                // root-gather form: a peer's accumulator copied to this device
     // progressive frame (rt_progressive_*): the running sums stay in device memory between passes; the session keeps its own
     // copy of the scene records so that the caller's may go away between passes
@@ -706,8 +709,10 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
+std::mutex g_rccl_mu;                              // g_rccl is process-wide: bound under this lock by every group that loads the library
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;      // rccl.h: ncclFloat32 = 7, ncclSum = 0
 bool rccl_bind(void* lib) {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
     auto sym = [&](const char* n) { return dlsym(lib, n); };
     g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
@@ -755,12 +760,14 @@ rt_ctx* rt_create(int32_t device_id) {
             unsigned char* ptr = nullptr;
             hipError_t se = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
             if (se != hipSuccess || !ptr) { g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se); rt_destroy(c); return nullptr; }
-            g_scratch_ptr[dev] = ptr;
+            hipEvent_t gev = nullptr;
+            if (hipEventCreateWithFlags(&gev, hipEventDisableTiming) != hipSuccess) { g_create_error = "hipEventCreate (scratch guard) failed"; rt_destroy(c); return nullptr; }
+            g_scratch_ptr[dev] = ptr; g_scratch_ev[dev] = gev;      // lives until the process ends, like the array
         }
         c->scratch_dev = dev < RT_MAX_DEVICES ? g_scratch_ptr[dev] : nullptr;
+        c->ev_scene_use_na = dev < RT_MAX_DEVICES ? g_scratch_ev[dev] : nullptr;
     }
-    if (hipHostMalloc(&c->h_stage_na, RT_NOALLOC_SCENE_BYTES, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_scene_use_na, hipEventDisableTiming) != hipSuccess) { g_create_error = "failed to create the allocation-free entry point's staging buffer"; rt_destroy(c); return nullptr; }
+    if (hipHostMalloc(&c->h_stage_na, RT_NOALLOC_SCENE_BYTES, hipHostMallocDefault) != hipSuccess) { g_create_error = "failed to create the allocation-free entry point's staging buffer"; rt_destroy(c); return nullptr; }
     memset(c->h_counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long));
     return c;
 }
@@ -769,6 +776,7 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     for (void* comm : c->comms) if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
     c->comms.clear();
+    if (c->rccl_lib) { (void)dlclose(c->rccl_lib); c->rccl_lib = nullptr; }      // dlopen counts references: the library stays while another group holds it
     for (size_t i = 0; i < c->peers.size(); ++i) {
         if (c->peer_done[i]) { (void)hipSetDevice(c->peers[i]->device); (void)hipEventDestroy(c->peer_done[i]); }
         rt_destroy(c->peers[i]);
@@ -786,7 +794,6 @@ void rt_destroy(rt_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_scene_use) (void)hipEventDestroy(c->ev_scene_use);
-    if (c->ev_scene_use_na) (void)hipEventDestroy(c->ev_scene_use_na);
     if (c->h_stage_na) (void)hipHostFree(c->h_stage_na);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -810,19 +817,27 @@ rt_ctx* rt_create_multi(const int32_t* device_ids, int32_t n_devices) {
     // Distinct devices: one RCCL communicator per device, a single process driving all of them (ncclCommInitAll); the per-GPU
     // accumulators are then combined with ONE all-reduce over xGMI.  The same device listed twice (a one-GPU rehearsal of the
     // group code) cannot form a communicator: the sums then go through the root-gather form (copy to device_ids[0], add).
+    // RCCL that cannot be loaded or initialised is not an error: the root-gather form needs none of it.
+    c->group_note = n_devices == 1 ? "one device: nothing to sum" : !distinct ? "a device is listed twice: root-gather form (copies to the first device, added in a fixed order)"
+                  : getenv("RT_MI355_NO_RCCL") ? "RT_MI355_NO_RCCL is set: root-gather form" : "";
     if (distinct && n_devices > 1 && !(getenv("RT_MI355_NO_RCCL"))) {
-        c->rccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!c->rccl_lib) c->rccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        const char* libname = getenv("RT_MI355_RCCL_LIB");      // test hook: another library name (a name that cannot be loaded exercises the fallback)
+        c->rccl_lib = dlopen(libname ? libname : "librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!c->rccl_lib && !libname) c->rccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!c->rccl_lib || !rccl_bind(c->rccl_lib)) {
             const char* why = dlerror();                 // one call: dlerror() clears the message it returns
-            g_create_error = std::string("rt_create_multi: cannot load RCCL (librccl.so): ") + (why ? why : "missing symbols");
-            rt_destroy(c); return nullptr;
+            c->group_note = std::string("RCCL not usable (") + (why ? why : "missing symbols") + "): root-gather form";
+            if (c->rccl_lib) { (void)dlclose(c->rccl_lib); c->rccl_lib = nullptr; }
+        } else {
+            c->comms.assign((size_t)n_devices, nullptr);
+            std::vector<int> devs(device_ids, device_ids + n_devices);
+            int r = g_rccl.CommInitAll(c->comms.data(), n_devices, devs.data());
+            if (r != 0) {
+                c->group_note = std::string("ncclCommInitAll failed (") + g_rccl.GetErrorString(r) + "): root-gather form";
+                c->comms.clear();
+            } else c->group_note = "one grouped ncclAllReduce(sum, float32) over a single-process communicator";
+            (void)hipSetDevice(c->device);
         }
-        c->comms.assign((size_t)n_devices, nullptr);
-        std::vector<int> devs(device_ids, device_ids + n_devices);
-        int r = g_rccl.CommInitAll(c->comms.data(), n_devices, devs.data());
-        if (r != 0) { g_create_error = std::string("rt_create_multi: ncclCommInitAll: ") + g_rccl.GetErrorString(r); c->comms.clear(); rt_destroy(c); return nullptr; }
-        (void)hipSetDevice(c->device);
     }
     return c;
 }
@@ -1326,6 +1341,12 @@ int32_t rt_debug_strict_slots(const rt_scene* scene, int32_t variant, int32_t* o
     for (const int4& r : H.sruns) if (is_strict_type(r.x)) n[r.x - PRIM_PLANE_STRICT] += r.z;
     if (out) { out[0] = n[0]; out[1] = n[1]; out[2] = n[2]; }
     return n[0] + n[1] + n[2];
+}
+// how a device group sums its accumulators: 1 = RCCL all-reduce, 0 = root-gather form (or a single device); note: why
+int32_t rt_debug_group_mode(const rt_ctx* c, char* note, int32_t cap) {
+    if (!c) return -1;
+    if (note && cap > 0) { strncpy(note, c->group_note.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
+    return c->comms.empty() ? 0 : 1;
 }
 // the device group's partition of a sample range (rt_create_multi); needs no GPU
 int32_t rt_debug_group_share(int32_t s0, int32_t s1, int32_t i, int32_t n, int32_t* b, int32_t* e) {

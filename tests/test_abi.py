@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol():
     assert L.rt_abi_version() == 2
 
 
+def test_every_exported_symbol_is_declared_in_a_header():
+    """The diagnostic exports (rt_debug_*) are declared in include/rt_mi355_debug.h, apart from the boundary: every rt_* symbol
+    the library exports has a declaration in one of the two headers, and every declared one is exported."""
+    import subprocess
+    text = open(os.path.join(ROOT, "include", "rt_mi355_debug.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    dbg = sorted(set(re.findall(r"\b(rt_debug_[a-z_]+)\s*\(", text)))
+    assert dbg and all(n.startswith("rt_debug_") for n in dbg)
+    L = lib.load()
+    for name in dbg:
+        assert hasattr(L, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("rt_") and ln.split()[-2] in "TW"})
+    assert exported == sorted(set(dbg) | set(_declared())), set(exported) ^ (set(dbg) | set(_declared()))
+
+
 def test_record_sizes_match_header():
     assert C.sizeof(abi.rt_prim) == 64 and C.sizeof(abi.rt_material) == 48 and C.sizeof(abi.rt_light) == 32
     assert C.sizeof(abi.rt_path_params) == 32 and C.sizeof(abi.rt_whitted_params) == 16
@@ -134,6 +150,15 @@ def test_device_group_partition_covers_every_sample_once():
                 cur = e.value; sizes.append(e.value - b.value)
             assert cur == s1 and max(sizes) - min(sizes) <= 1
     assert L.rt_debug_group_share(0, 4, 2, 2, C.byref(b), C.byref(e)) == abi.RT_ERR_BAD_ARG
+
+
+def test_device_group_argument_errors_need_no_gpu():
+    """rt_create_multi refuses a null list and counts outside [1, 64] before it touches any device, with a message."""
+    L = lib.load()
+    ids = (C.c_int32 * 70)(*range(70))
+    for args in ((None, 2), (ids, 0), (ids, -1), (ids, 65)):
+        assert not L.rt_create_multi(args[0], args[1])
+        assert b"rt_create_multi" in L.rt_last_error(None)
 
 
 def test_prefer_system_compiler_is_safe_to_call_any_time():

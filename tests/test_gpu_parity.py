@@ -593,6 +593,42 @@ def test_device_group_equals_single_device(ctx):
         grp.close()
 
 
+def test_device_group_error_paths_and_fallbacks(ctx, monkeypatch):
+    """rt_create_multi on the one-GPU box: a device id beyond the device count is refused with the device named; a device
+    listed twice, RT_MI355_NO_RCCL and an RCCL library that cannot be loaded all end in the root-gather form (never an
+    error), and the group says which and why (rt_debug_group_mode)."""
+    import torch
+    L = lib.load()
+    L.rt_debug_group_mode.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    n_dev = torch.cuda.device_count()
+    bad = (C.c_int32 * 2)(0, n_dev)
+    assert not L.rt_create_multi(bad, 2) and b"out of range" in L.rt_last_error(None)
+    bad = (C.c_int32 * 2)(0, -7)      # negative ids mean "current device" to rt_create: the group then lists device 0 twice
+    note = C.create_string_buffer(512)
+
+    def mode(devs):
+        g = lib.Context(devices=devs)
+        try:
+            m = L.rt_debug_group_mode(g.h, note, 512)
+            s, cam, prm = scenes.scene04(6, seed=2)
+            r = g.render_path(s, cam, prm, 64, 48)
+            one = ctx.render_path(s, cam, prm, 64, 48)
+            assert r["rays"] == one["rays"] and np.allclose(r["rgb"], one["rgb"], rtol=1e-5, atol=1e-7)
+        finally:
+            g.close()
+        return m, note.value.decode()
+
+    m, why = mode([0, 0]);  assert m == 0 and "listed twice" in why
+    m, why = mode([0]);     assert m == 0 and "one device" in why
+    monkeypatch.setenv("RT_MI355_NO_RCCL", "1")
+    m, why = mode([0, 0]);  assert m == 0
+    monkeypatch.delenv("RT_MI355_NO_RCCL")
+    if n_dev >= 2:            # distinct devices (not on the round's one-GPU boxes): RCCL, and its fallback when the library is missing
+        m, why = mode([0, 1]); assert m == 1 and "ncclAllReduce" in why
+        monkeypatch.setenv("RT_MI355_RCCL_LIB", "/nonexistent/librccl.so")
+        m, why = mode([0, 1]); assert m == 0 and "RCCL not usable" in why
+
+
 def test_resolve_is_bit_exact(ctx):
     import torch
     rng = np.random.default_rng(0)
