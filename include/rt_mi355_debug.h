@@ -18,7 +18,9 @@ extern "C" {
  *     64  02: shadow samples on the global-memory layout even when the slots fit LDS
  *    256  queue form of the bounce loop (path_queue_body)       512  one lane per pixel, per-lane regeneration (path_body)
  *   1024  item / sorted form whatever the frame size (default: only frames that can occupy the chip)
- *   2048  outcome-sorted form of the bounce loop (path_sorted_body) */
+ *   2048  outcome-sorted form of the bounce loop (path_sorted_body)
+ *   4096  02: the monolithic kernel even without a scene-specialised build
+ *   8192  02: the wavefront form of the Whitted kernel (tree walk -> shadow rays, several threads per request -> per-pixel combine) */
 int32_t rt_debug_set_flags(rt_ctx* ctx, int32_t flags);
 /* idle lanes per wave that trigger a regeneration pass; < 0 restores the default */
 int32_t rt_debug_set_regen_threshold(rt_ctx* ctx, int32_t n);
@@ -29,6 +31,8 @@ int32_t rt_debug_last_path_kernel(const rt_ctx* ctx, char* note, int32_t cap);
 int32_t rt_debug_last_path_form(const rt_ctx* ctx, int32_t* unit_log2);
 /* 2 scene-specialised (02 only), 1 generic */
 int32_t rt_debug_last_whitted_kernel(const rt_ctx* ctx);
+/* 1 wavefront form (tree walk -> one thread per shadow ray -> per-pixel combine), 0 monolithic kernel */
+int32_t rt_debug_last_whitted_form(const rt_ctx* ctx);
 /* how a device group sums its accumulators: 1 RCCL all-reduce, 0 root-gather form / single device; note: why */
 int32_t rt_debug_group_mode(const rt_ctx* ctx, char* note, int32_t cap);
 

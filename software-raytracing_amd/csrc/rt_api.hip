@@ -133,12 +133,14 @@ struct rt_ctx {
     unsigned char* scratch_dev = nullptr; void* h_stage_na = nullptr; hipEvent_t ev_scene_use_na = nullptr;      // the event is the DEVICE's (g_scratch_ev), not owned
     bool timing_pending = false;
     DevBuf scene_buf, partial, accum, bgra, rgb;
+    DevBuf wf_req, wf_words;                      // wavefront form of the Whitted kernels: the shadow requests (48 B each) and their prev / occ words + one head word per pixel
     unsigned long long* d_counters = nullptr;     // RT_COUNTER_BANKS x {rays, shadow rays}
     unsigned long long* h_counters = nullptr;     // pinned
     std::string jit_note;                         // why the last path render was not scene-specialised ("" = it was)
     int last_path_kernel = -1;                    // 3 BVH walk, 2 specialised, 1 generic LDS-resident, 0 tiled / global
     int last_path_form = -1, last_unit_log2 = 0;  // RT_FORM_* of the last path render; item form: log2 of the pixels per unit
     int last_whitted_kernel = -1;                 // 2 specialised (02 only), 1 generic
+    int last_whitted_form = -1;                   // 1 wavefront form (walk / shadow rays / combine), 0 monolithic kernel
     void* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned scene staging
     uint64_t pending_samples = 0;
     rt_stats stats{};
@@ -787,7 +789,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->ar1) (void)hipEventDestroy(c->ar1);
     c->gather.release();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->scene_buf.release(); c->partial.release(); c->accum.release(); c->bgra.release(); c->rgb.release(); c->prog_sum.release();
+    c->wf_req.release(); c->wf_words.release(); c->scene_buf.release(); c->partial.release(); c->accum.release(); c->bgra.release(); c->rgb.release(); c->prog_sum.release();
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1038,16 +1040,47 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
     A.w = w; A.h = h; A.tan_half = th; A.debug_flags = c->debug_flags;
     // 02: nearly every ray is a shadow sample; for small scenes their scene query is compiled for THIS scene like the path
     // kernels' (same policy, same switches: second render of a scene, a large job, debug flag 16 / RT_MI355_JIT=2; flag 8 / =0 off)
-    hipFunction_t jit = nullptr;
+    hipFunction_t jit = nullptr, jit_stage2 = nullptr;
     const char* jit_env = getenv("RT_MI355_JIT");
     c->jit_note.clear();
     if (p->shadow_samples > 0 && !(c->debug_flags & 8) && !(jit_env && jit_env[0] == '0') &&
         jit_wanted(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, (double)width * height * p->shadow_samples * (scene->n_lights > 0 ? scene->n_lights : 1),
                    (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
-        jit = jit_path_kernel(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, 0.01f, 1000.0f, RT_FORM_REGEN, c->jit_note);
+        jit = jit_path_kernel(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, 0.01f, 1000.0f, RT_FORM_REGEN, c->jit_note, &jit_stage2);
     c->last_whitted_kernel = jit ? 2 : 1;
+    // Wavefront form (rt_whitted_device.h; debug flag 8192 or RT_MI355_WHITTED=w): the tree walk emits shadow REQUESTS, a second
+    // kernel traces them with 2^g threads per request, a third adds their contributions per pixel.  Request slots: one per (pixel,
+    // light) for primary hits + room for deeper tree nodes (a pixel that needs more is rendered by the monolithic kernel in a last
+    // pass).  Not the default: on the reference's closed room every lane of the monolithic kernel is busy through its shadow
+    // loop, and the stages' extra launches and request traffic cost more than they return.
+    // 02 only: with ONE shadow ray per hit (01) the stages have nothing to parallelise and three launches cost more than the frame.
+    const char* wf_env = getenv("RT_MI355_WHITTED");
+    // Default: the scene-specialised monolithic kernel when there is one (no scratch at 7 waves per SIMD, the fastest form measured);
+    // without it - the first render of a scene, scenes beyond 64 primitives - the wavefront form, whose generic kernels need no
+    // scratch either (the generic monolithic 02 kernel spills 168 B per lane); debug flag 4096 forces the monolithic kernel.
+    const bool wavefront = p->shadow_samples > 0 && ((c->debug_flags & 8192) || (wf_env && wf_env[0] == 'w') || (!jit && !(c->debug_flags & 4096))) && scene->n_lights >= 1 && scene->n_lights <= 32 &&
+                           (long long)width * height * scene->n_lights * 2 * 64 < (1LL << 32);
+    c->last_whitted_form = wavefront ? 1 : 0;
+    bool overflow_impossible = false;
+    if (wavefront) {
+        // deeper nodes: the worst case of a non-branching tree (max_depth further shaded nodes per pixel) when that is modest, else a quarter of the primary slots
+        const size_t base = (size_t)width * height * (size_t)scene->n_lights, worst = H.whitted_branches ? (size_t)-1 : base * (size_t)p->max_depth;
+        bool any_secondary = false;
+        for (int m = 0; m < scene->n_materials; ++m) any_secondary = any_secondary || scene->materials[m].primary_to_secondary < 1.0f;
+        size_t extra = base / 4 + 4096;
+        if (!any_secondary) { extra = 64; overflow_impossible = true; }                                  // no material spawns a secondary ray: primary hits only
+        else if (worst != (size_t)-1 && (base + worst) * 56 <= ((size_t)256 << 20)) { extra = worst; overflow_impossible = true; }
+        const size_t slots = base + extra;
+        HIPCHK(c, c->wf_req.reserve(slots * 48));
+        HIPCHK(c, c->wf_words.reserve((2 * slots + (size_t)width * height) * 4));
+        A.wf_req = (float4*)c->wf_req.p;
+        A.wf_prev = (uint32_t*)c->wf_words.p; A.wf_occ = A.wf_prev + slots; A.wf_head = A.wf_occ + slots;
+        A.wf_counter = reinterpret_cast<uint32_t*>(c->d_counters + RT_WORK_COUNTER + 1);      // cleared with the ray counters by begin_timed
+        A.wf_base = (uint32_t)base; A.wf_capacity = (uint32_t)extra;
+    }
     if ((rc = begin_timed(c, st))) return rc;      // after a possible compile
-    launch_whitted(p->shadow_samples > 0, D, A, (float4*)d_color, c->d_counters, st, jit);
+    if (wavefront) launch_whitted_wavefront(true, D, A, (float4*)d_color, c->d_counters, st, jit_stage2, c->n_cus * 8, overflow_impossible);
+    else launch_whitted(p->shadow_samples > 0, D, A, (float4*)d_color, c->d_counters, st, jit);
     HIPCHK(c, hipGetLastError());
     c->pending_samples = (uint64_t)width * height;
     return end_timed(c, st);
@@ -1263,6 +1296,7 @@ int32_t rt_debug_last_path_kernel(const rt_ctx* c, char* note, int32_t cap) {
     return c->last_path_kernel;
 }
 int32_t rt_debug_last_whitted_kernel(const rt_ctx* c) { return c ? c->last_whitted_kernel : -1; }
+int32_t rt_debug_last_whitted_form(const rt_ctx* c) { return c ? c->last_whitted_form : -1; }
 // which form of the bounce loop rendered the last path image: 0 per-lane regeneration (one lane per pixel), 1 queue form, 2 item
 // form (persistent waves + work counter); unit_log2: item form, log2 of the pixels per unit of work
 int32_t rt_debug_last_path_form(const rt_ctx* c, int32_t* unit_log2) { if (!c) return -1; if (unit_log2) *unit_log2 = c->last_unit_log2; return c->last_path_form; }

@@ -49,5 +49,13 @@ struct WhittedArgs {
     float w, h, tan_half;           // float(width), float(height), tanf(fovRadians/2) (01 Main.cpp:329-341)
     int stack_bytes, shadow_lds;    // set by launch_whitted: LDS bytes of the recursion stack; slot layout staged behind it for 02's shadow samples
     int debug_flags;                // bit 6 (64): 02's shadow samples on the global-memory layout even when the slots would fit LDS (A/B switch)
+    // wavefront form (rt_whitted_device.h): the tree walk emits one REQUEST per (shaded hit, light) instead of tracing the shadow
+    // rays itself; requests: 3 float4 each, wf_prev / wf_occ one word each, wf_head one word per pixel, wf_counter one word
+    float4* wf_req; uint32_t* wf_prev; uint32_t* wf_occ; uint32_t* wf_head; uint32_t* wf_counter;
+    uint32_t wf_base, wf_capacity;  // slots [0, wf_base): one per (pixel, light) for primary hits; [wf_base, wf_base + wf_capacity): deeper nodes, allocated through wf_counter
+    int wf_group_log2;              // stage 2, 02: 2^wf_group_log2 threads share a request's samples
+    int only_marked;                // monolithic kernel: render only the pixels whose wf_head says "overflowed"
 };
+#define RT_WF_NONE 0xFFFFFFFFU       /* wf_head / wf_prev: end of a pixel's request chain */
+#define RT_WF_OVERFLOW 0xFFFFFFFEU   /* wf_head: the request buffer was full; the monolithic kernel renders this pixel */
 } // namespace rt

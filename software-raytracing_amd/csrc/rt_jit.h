@@ -11,7 +11,8 @@ constexpr int RT_JIT_WHITTED_SOFT = 2;   // 'variant' of the 02 kernel (3 and 4 
 // Policy: whether this render should use (and, if need be, compile) the specialised kernel; counts sightings of the scene.
 bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, double job_samples, bool force, std::string& note);
 // tmin / tmax: the range of the path query (literals of the generated code; ignored by the 02 kernel, whose shadow rays carry their own)
-hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note);
+hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note, hipFunction_t* second = nullptr);
+// second (02 only): the module's other kernel, stage 2 of the wavefront form (k_whitted_shadow_jit)
 // form: which body the kernel wraps - RT_FORM_REGEN path_body (per-lane regeneration), RT_FORM_QUEUE path_queue_body (workgroup-level
 // ray-queue compaction), RT_FORM_ITEMS path_items_body (persistent waves, work counter, lanes decoupled from pixels)
 // RT_FORM_SORTED path_sorted_body (the workgroup sorts its paths by the outcome of the scene query)

@@ -263,7 +263,7 @@ uint64_t fnv1a(const std::string& s) {
     return h;
 }
 
-struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::string note; };
+struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn2 = nullptr; std::string note; };      // fn2: the 02 module's second kernel (stage 2 of the wavefront form)
 std::mutex g_mu;
 std::map<std::pair<int, uint64_t>, Entry> g_cache;   // (device, source hash)
 
@@ -288,7 +288,8 @@ bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector
     return false;
 }
 
-hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note) {
+hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note, hipFunction_t* second) {
+    if (second) *second = nullptr;
     size_t n_prims = 0;
     for (const int4& r : sruns) n_prims += (size_t)r.z;
     if (n_prims == 0 || n_prims > RT_JIT_MAX_PRIMS) { note = "scene has " + std::to_string(n_prims) + " slots (specialised up to " + std::to_string(RT_JIT_MAX_PRIMS) + ")"; return nullptr; }
@@ -309,10 +310,16 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     const bool gen2 = variant != RT_JIT_WHITTED_SOFT && gen_env && (gen_env[0] == '2' || gen_env[0] == '3') && tmin >= 0.0f && tmax > tmin && std::isfinite(tmax) && !has_strict;
     src += (gen2 ? gen_closest_hit_v2(slots, sruns, tmin, tmax, gen_env[0] == '3') : gen_closest_hit(slots, sruns)) + gen_any_hit(slots, sruns);
     const char* entry = variant == RT_JIT_WHITTED_SOFT ? "k_whitted_jit" : "k_path_jit";
-    if (variant == RT_JIT_WHITTED_SOFT)   // 02: the generated query serves the shadow samples of whitted_body<true>
+    if (variant == RT_JIT_WHITTED_SOFT) {   // 02: the generated any-hit query serves the shadow samples - of the monolithic kernel (k_whitted_jit) and of stage 2 of the wavefront form (k_whitted_shadow_jit)
+        // waves per SIMD of the monolithic kernel: 7 (72 VGPRs) needs no scratch; 8 (64 VGPRs) spills a few cold values (RT_MI355_WHITTED_WAVES, measured: DESIGN.md 3)
+        const char* wv = getenv("RT_MI355_WHITTED_WAVES");
+        const std::string waves = (wv && wv[0] >= '4' && wv[0] <= '8' && !wv[1]) ? std::string(wv) : "7";
         src += std::string(kSrcStrict) + "\n" + kSrcWhitted +
-            "\nextern \"C\" __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted_jit(rt::DevScene SD, rt::WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
-            "    rt::whitted_body<true>(SD, A, out, counters);\n}\n";
+            "\nextern \"C\" __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(" + waves + ", 8))) void k_whitted_jit(rt::DevScene SD, rt::WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
+            "    rt::whitted_body<true>(SD, A, out, counters);\n}\n"
+            "\nextern \"C\" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted_shadow_jit(rt::DevScene SD, rt::WhittedArgs A) {\n"
+            "    rt::whitted_shadow_body<true>(SD, A);\n}\n";
+    }
     else
         src += std::string(kSrcPath) +
             "\nextern \"C\" __global__ __launch_bounds__(256) void k_path_jit(rt::DevScene SD, rt::PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
@@ -321,7 +328,7 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     const auto key = std::make_pair(dev, fnv1a(src));
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
-    if (it != g_cache.end()) { note = it->second.note; return it->second.fn; }
+    if (it != g_cache.end()) { note = it->second.note; if (second) *second = it->second.fn2; return it->second.fn; }
     if (g_cache.size() >= RT_JIT_MAX_SCENES) { note = "more than " + std::to_string(RT_JIT_MAX_SCENES) + " distinct scenes in this process: generic kernel"; return nullptr; }
     Entry e;
     hiprtcProgram prog = nullptr;
@@ -346,11 +353,13 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
                 if (FILE* f = fopen((std::string(dump) + ".co").c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
             }
             if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, entry) != hipSuccess) { e.fn = nullptr; e.note = "hipModuleLoadData/GetFunction failed"; }
+            else if (variant == RT_JIT_WHITTED_SOFT && hipModuleGetFunction(&e.fn2, e.mod, "k_whitted_shadow_jit") != hipSuccess) e.fn2 = nullptr;
         }
         hiprtcDestroyProgram(&prog);
     }
     g_cache[key] = e;
     note = e.note;
+    if (second) *second = e.fn2;
     return e.fn;
 }
 

@@ -18,5 +18,7 @@ void launch_add_image(float4* dst, const float4* src, int n_pixels, hipStream_t 
 void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* out, hipStream_t st);
 // jit: scene-specialised 02 kernel (rt_jit.h) or nullptr
 void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st, hipFunction_t jit);
+// wavefront form of the Whitted kernels: tree walk -> one thread per shadow ray -> per-pixel combine (+ the monolithic kernel over overflowed pixels)
+void launch_whitted_wavefront(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st, hipFunction_t jit, int grid_blocks, bool overflow_impossible);
 void launch_resolve(const float4* accum, int width, int height, float divisor, int gamma, uint8_t* bgra, int stride, float* rgb, hipStream_t st);
 } // namespace rt

@@ -130,9 +130,62 @@ void launch_sum_slices(const float4* part, int n_pixels, int n_slices, float4* o
 // =================================================================================================
 // 8 waves/SIMD (64 VGPRs, a few cold values spilled): this kernel is bound by dependent-issue latency, not registers:
 // measured 02 4K/256 samples 10.5 ms at 4 waves, 9.3 at 5, 8.7 at 6, 8.3 at 8
+__global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted_soft(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    whitted_body<true>(SD, A, out, counters);
+}
+// 01 (one shadow ray per shaded hit and light): a frame is a fraction of a millisecond, bound by launch and latency, and the
+// kernel takes the registers it needs (no scratch) rather than 8 waves per SIMD
+__global__ __launch_bounds__(WBLOCK) void k_whitted_hard(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    whitted_body<false>(SD, A, out, counters);
+}
+
+// Wavefront form (rt_whitted_device.h): walk -> shadow rays, one thread each -> combine.
+// the walk traces one closest-hit query per tree node and no shadow ray: it is latency-tolerant, so it takes the registers it needs (no scratch) instead of 8 waves per SIMD
+__global__ __launch_bounds__(WBLOCK) void k_whitted_walk(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    whitted_body<false, true>(SD, A, out, counters);
+}
 template <bool SOFT>
-__global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted(DevScene SD, WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
-    whitted_body<SOFT>(SD, A, out, counters);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted_shadow(DevScene SD, WhittedArgs A) { whitted_shadow_body<SOFT>(SD, A); }
+template <bool SOFT>
+__global__ __launch_bounds__(256) void k_whitted_combine(WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) { whitted_combine_body<SOFT>(A, out, counters); }
+
+// A.wf_* set by the caller.  grid_blocks: what the device holds at once (stage 2 is a grid-stride loop over the requests).
+void launch_whitted_wavefront(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st, hipFunction_t jit, int grid_blocks, bool overflow_impossible) {
+    const int n_pixels = A.width * A.height;
+    WhittedArgs B = A;
+    B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : 0;
+    B.shadow_lds = 0; B.only_marked = 0;
+    hipLaunchKernelGGL(k_whitted_walk, dim3(((A.width + 15) / 16) * ((A.height + 7) / 8)), dim3(WBLOCK), (size_t)B.stack_bytes, st, S, B, out, counters);
+    // threads of stage 2: 2^g per request - enough of them to occupy the chip (~2M) on small frames, but at least 4 samples each
+    // (a thread's set-up - request, light, keys - is a chain of dependent loads: short threads are bound by its latency)
+    int g = 0;
+    if (soft) while (g < 6 && (8 << g) <= A.shadow_samples && (((unsigned long long)A.wf_base + A.wf_capacity) << g) < (2ULL << 20)) ++g;
+    B.wf_group_log2 = g;
+    const unsigned long long max_threads = ((unsigned long long)A.wf_base + A.wf_capacity) << g;
+    const unsigned blocks = (unsigned)std::max<unsigned long long>(1ULL, std::min<unsigned long long>((max_threads + 255) / 256, (unsigned long long)grid_blocks * 4));
+    WhittedArgs C = B;
+    C.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed && !(A.debug_flags & 64);
+    bool done = false;
+    if (soft && jit) {   // scene-specialised stage 2: its any-hit query is generated code, nothing to stage
+        WhittedArgs J = C; J.shadow_lds = 0;
+        DevScene s = S;
+        void* params[] = {&s, &J};
+        done = hipModuleLaunchKernel(jit, blocks, 1, 1, 256, 1, 1, 0, st, params, nullptr) == hipSuccess;
+        if (!done) (void)hipGetLastError();
+    }
+    if (!done) {
+        const size_t lds = C.shadow_lds ? (size_t)S.slot_bytes + 256 : 0;
+        if (soft) hipLaunchKernelGGL(k_whitted_shadow<true>, dim3(blocks), dim3(256), lds, st, S, C);
+        else      hipLaunchKernelGGL(k_whitted_shadow<false>, dim3(blocks), dim3(256), 0, st, S, C);
+    }
+    if (soft) hipLaunchKernelGGL(k_whitted_combine<true>, dim3((n_pixels + 255) / 256), dim3(256), 0, st, B, out, counters);
+    else      hipLaunchKernelGGL(k_whitted_combine<false>, dim3((n_pixels + 255) / 256), dim3(256), 0, st, B, out, counters);
+    // pixels whose requests did not fit the queue: the monolithic kernel renders them whole (it exits at once everywhere else);
+    // not needed when the queue holds the worst case (every pixel's walk shading max_depth + 1 nodes)
+    if (!overflow_impossible) {
+        WhittedArgs M = A; M.only_marked = 1;
+        launch_whitted(soft, S, M, out, counters, st, nullptr);
+    }
 }
 
 void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* out, unsigned long long* counters, hipStream_t st, hipFunction_t jit) {
@@ -150,8 +203,8 @@ void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* 
         (void)hipGetLastError();   // could not launch it: the generic kernel below renders the same image
     }
     size_t lds = (size_t)B.stack_bytes + (B.shadow_lds ? (size_t)S.slot_bytes + 256 : 0);   // + the leading empty slot (address 0 = "no hit") and a wide slot of slack for read-ahead
-    if (soft) hipLaunchKernelGGL(k_whitted<true>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
-    else      hipLaunchKernelGGL(k_whitted<false>, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
+    if (soft) hipLaunchKernelGGL(k_whitted_soft, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
+    else      hipLaunchKernelGGL(k_whitted_hard, grid, dim3(WBLOCK), lds, st, S, B, out, counters);
 }
 
 // =================================================================================================

@@ -8,7 +8,15 @@
 namespace rt {
 
 #define WBLOCK 128
-template <bool SOFT>
+// WALK = false: the whole of TraceTay in one kernel (shadow rays traced where the hit is shaded).
+// WALK = true: stage 1 of the WAVEFRONT form - the tree walk only.  Where TraceTay traces the shadow rays of a shaded hit
+// (01 Main.cpp:435-436, 02 Main.cpp:452-467) this stage writes a request {hit point, pixel, unshadowed contribution of the light,
+// tree node | light, direction and distance to the light} to a queue in HBM and goes on with the tree; stage 2
+// (whitted_shadow_body) traces the requests' shadow rays with one thread per ray - the whole chip works on them even when the
+// frame has few pixels - and counts the occluded ones per request; stage 3 (whitted_combine_body) adds every request's
+// contribution, scaled by its visibility, to its pixel in the order the walk emitted them.  The walk needs none of the shadow
+// query's registers (round 2: 168 B per lane of scratch in 02's kernel, 56 B in 01's, at the 64 VGPRs of 8 waves per SIMD).
+template <bool SOFT, bool WALK = false>
 __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     const Scn S = scn_over(SD, SD.blob);
     // slot k (k = depth of the parked child, 1..max_depth+1): o(3) d(3) weight node, one column per thread; sized by the
@@ -39,9 +47,14 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
     int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     int px = tx * 16 + (tid >> 6) * 8 + (tid & 7), py = ty * 8 + ((tid & 63) >> 3);
     bool inside = px < A.width && py < A.height;
+    const bool in_frame = inside;
     const uint32_t pixel = (uint32_t)(py * A.width + px);
     const uint32_t skey = rng_sample_key(rng_pixel_key(A.seed, pixel), 0U);
 
+    if (!WALK && A.only_marked) inside = inside && A.wf_head[pixel] == RT_WF_OVERFLOW;      // second pass: pixels whose requests did not fit the queue
+    uint32_t wf_head = RT_WF_NONE;      // WALK: the pixel's latest request (a chain through wf_prev, newest first)
+    bool wf_overflow = false;
+    uint32_t base_used = 0U;            // WALK: which of the pixel's primary-hit slots (one per light) hold a request
     f3 o = F3(0, 0, 0), d = strict::primary_dir(px, py, A.w, A.h, A.tan_half);     // 01 Main.cpp:340-344
     float weight = 1.0f, tmin = 0.0f;
     int depth = 0;
@@ -75,7 +88,34 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                         float len = strict::length(to);
                         float intensity = 1.0f;
                         bool skip = false;
-                        if (!SOFT) {                                                                     // 01 :435-436
+                        if (WALK) {
+                            if (depth + 1 <= A.max_depth) {      // shadow rays apply: hand the light's contribution to the shadow stage
+                                float dd = fmaxf(0.0f, strict::dot(tod, n));
+                                float sdot = fmaxf(0.0f, strict::dot(strict::reflect(-tod, n), -d));
+                                float sp = powf(sdot, m1.y);
+                                const f3 cl = (F3(l1) * dd * F3(m0) + F3(l1) * sp * m1.x) * (weight * (1.0f - wp));
+                                // slot: a primary hit's request sits at pixel * lights + light (no atomic: 8 million of them on one
+                                // counter would cost more than the frame); deeper nodes draw from the region behind, one atomic per wave
+                                uint32_t slot;
+                                if (node == 1U && li < 32) { slot = pixel * (uint32_t)S.n_lights + (uint32_t)li; base_used |= 1U << li; }
+                                else {
+                                    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);      // the lanes that are here together
+                                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0U));
+                                    uint32_t b0 = 0U;
+                                    if (rank == 0U) b0 = atomicAdd(A.wf_counter, (uint32_t)__popcll(m));
+                                    b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+                                    slot = b0 + rank < A.wf_capacity ? A.wf_base + b0 + rank : 0xFFFFFFFFU;
+                                }
+                                if (slot != 0xFFFFFFFFU) {
+                                    A.wf_req[3 * (size_t)slot] = make_float4(p.x, p.y, p.z, __uint_as_float(pixel));
+                                    A.wf_req[3 * (size_t)slot + 1] = make_float4(cl.x, cl.y, cl.z, __uint_as_float((node << 16) | (uint32_t)li));
+                                    A.wf_req[3 * (size_t)slot + 2] = make_float4(tod.x, tod.y, tod.z, len);
+                                    A.wf_prev[slot] = wf_head; A.wf_occ[slot] = 0U;
+                                    wf_head = slot;
+                                } else wf_overflow = true;
+                                continue;
+                            }
+                        } else if (!SOFT) {                                                                     // 01 :435-436
                             if (depth + 1 <= A.max_depth) { ++srays; skip = strict::any_hit(S, p, tod, 0.01f, len); }
                         } else if (depth + 1 <= A.max_depth) {                                           // 02 :452-467, :539-566
                             float per = 1.0f / (float)A.shadow_samples;
@@ -148,8 +188,105 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
             }
         }
     }
+    if (WALK) {
+        if (in_frame) {
+            A.wf_head[pixel] = wf_overflow ? RT_WF_OVERFLOW : wf_head;
+            for (int li = 0; li < S.n_lights; ++li)      // primary-hit slots without a request (sky, a material without a primary term, an overflowed pixel) are marked empty
+                if (wf_overflow || !((base_used >> li) & 1U)) A.wf_req[3 * ((size_t)pixel * S.n_lights + li) + 1].w = __uint_as_float(0xFFFFFFFFU);
+        }
+        if (wf_overflow) rays = 0;      // the monolithic pass renders (and counts) this pixel from scratch
+    }
     if (inside) out[pixel] = make_float4(acc.x, acc.y, acc.z, 1.0f);
     wave_add_u64(counters + 2 * (blockIdx.x % RT_COUNTER_BANKS), rays);
+    wave_add_u64(counters + 2 * (blockIdx.x % RT_COUNTER_BANKS) + 1, srays);
+}
+
+// Stage 2 of the wavefront form: one thread per shadow ray (SOFT: request x sample, the samples of a request side by side;
+// else one ray per request), a grid-stride loop over however many requests stage 1 emitted.  The same arithmetic as the
+// monolithic kernel's shadow code: strict any-hit for 01 (its result gates the light), the fast tests for 02's samples.
+template <bool SOFT>
+__device__ __forceinline__ void whitted_shadow_body(const DevScene& SD, const WhittedArgs& A) {
+    const Scn S = scn_over(SD, SD.blob);
+    extern __shared__ float lds_raw[];
+    const SceneMem<true> T{reinterpret_cast<const char*>(lds_raw)};
+    const uint32_t sh_slots = T.at((uint32_t)SLOT_BYTES);      // no slot at LDS address 0 (0 = "nothing hit")
+    const int4* __restrict__ sruns = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
+#ifndef RT_JIT_SCENE
+    if (SOFT && A.shadow_lds) {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_raw) + SLOT_BYTES);
+        const float4* src = SD.blob + SD.off_slots;
+        for (int i = threadIdx.x; i < (SD.slot_bytes >> 4); i += 256) dst[i] = src[i];
+        __syncthreads();
+    }
+#else
+    (void)T; (void)sh_slots; (void)sruns;
+#endif
+    const uint32_t n_req = A.wf_base + min(*A.wf_counter, A.wf_capacity);      // the primary-hit slots (one per pixel and light, some empty) + the deeper nodes' requests
+    // SOFT: G = 2^g threads share a request (g = A.wf_group_log2, G <= min(samples, 64)); thread j of them traces samples j, j + G, ...
+    const int g = SOFT ? A.wf_group_log2 : 0;
+    const uint32_t n_threads = n_req << g;      // < 2^32: the host checks
+    for (uint32_t it = blockIdx.x * 256U + threadIdx.x; it < n_threads; it += gridDim.x * 256U) {
+        const uint32_t slot = it >> g;
+        const float4 ra = A.wf_req[3 * (size_t)slot], rb = A.wf_req[3 * (size_t)slot + 1], rc = A.wf_req[3 * (size_t)slot + 2];
+        if (__float_as_uint(rb.w) == 0xFFFFFFFFU) continue;      // an empty primary-hit slot
+        const f3 p = F3(ra), tod = F3(rc);
+        const float len = rc.w;
+        uint32_t n_occ = 0U;
+        if (!SOFT) n_occ = strict::any_hit(S, p, tod, 0.01f, len) ? 1U : 0U;                            // 01 :435-436
+        else {                                                                                           // 02 :452-467, :539-566
+            const uint32_t pixel = __float_as_uint(ra.w), meta = __float_as_uint(rb.w);
+            const uint32_t node = meta >> 16, li = meta & 0xFFFFU;
+            const uint32_t skey = rng_sample_key(rng_pixel_key(A.seed, pixel), 0U);
+            const float4 l0 = S.lights[2 * li];
+            const float tmax_s = len - l0.w, radius_s = l0.w * (1.0f / 65536.0f);
+            const uint32_t c0 = (node * (uint32_t)S.n_lights + li) * (uint32_t)A.shadow_samples;
+            for (uint32_t i = it & ((1U << g) - 1U); i < (uint32_t)A.shadow_samples; i += 1U << g) {
+                const uint32_t c = (c0 + i) * 4U;
+                float k0, k1, k2, k3;
+                rng_pair_raw(skey, c, k0, k1); rng_pair_raw(skey, c + 2U, k2, k3);
+                const f3 sd = fastshadow::to_light_disk_raw(p, F3(l0), tod, radius_s, k0, k1, k2, k3);
+                bool occluded;
+#ifdef RT_JIT_SCENE
+                occluded = any_hit_jit(p, sd, 0.01f, 0.01f, tmax_s);
+#else
+                if (A.shadow_lds) {
+                    float closest = tmax_s; uint32_t best = 0U;
+                    closest_hit_runs<true, true>(T, sruns, SD.n_sruns, sh_slots, p, sd, F3(rcp_fast(sd.x), rcp_fast(sd.y), rcp_fast(sd.z)), 0.01f, 0.01f, closest, best, SD.srun_pack[0], SD.srun_pack[1]);
+                    occluded = best != 0U;
+                } else occluded = fastshadow::any_hit(S, p, sd, 0.01f, tmax_s);
+#endif
+                n_occ += occluded ? 1U : 0U;
+            }
+        }
+        if (n_occ) atomicAdd(&A.wf_occ[slot], n_occ);      // an integer count: order-independent
+    }
+}
+
+// Stage 3: one thread per pixel adds its requests' contributions, each scaled by its visibility - 02: intensity = 1 - 1/S per
+// occluded sample, subtracted one by one as the reference does (02 Main.cpp:465); 01: an occluded light is skipped (:437) -
+// newest request first, a fixed order per pixel; and counts the shadow rays of the requests it owns.
+template <bool SOFT>
+__device__ __forceinline__ void whitted_combine_body(const WhittedArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+    const uint32_t pixel = blockIdx.x * 256U + threadIdx.x;
+    unsigned int srays = 0;
+    if (pixel < (uint32_t)A.width * (uint32_t)A.height) {
+        uint32_t h = A.wf_head[pixel];
+        if (h != RT_WF_NONE && h != RT_WF_OVERFLOW) {
+            float4 px = out[pixel];
+            f3 acc = F3(px);
+            const float per = 1.0f / (float)A.shadow_samples;
+            while (h != RT_WF_NONE) {
+                const float4 rb = A.wf_req[3 * (size_t)h + 1];
+                const uint32_t occ = A.wf_occ[h];
+                float intensity = 1.0f;
+                if (SOFT) { for (uint32_t k = 0; k < occ; ++k) intensity -= per; srays += (unsigned int)A.shadow_samples; }
+                else { intensity = occ ? 0.0f : 1.0f; ++srays; }
+                acc = madd(F3(rb), intensity, acc);
+                h = A.wf_prev[h];
+            }
+            out[pixel] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+        }
+    }
     wave_add_u64(counters + 2 * (blockIdx.x % RT_COUNTER_BANKS) + 1, srays);
 }
 

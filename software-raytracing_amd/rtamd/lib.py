@@ -74,6 +74,7 @@ def load():
         L.rt_debug_set_flags.argtypes = [C.c_void_p, C.c_int32]
         L.rt_debug_last_path_kernel.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
         L.rt_debug_last_whitted_kernel.argtypes = [C.c_void_p]
+        L.rt_debug_last_whitted_form.argtypes = [C.c_void_p]
         L.rt_debug_last_path_form.argtypes = [C.c_void_p, P(C.c_int32)]
         _LIB = L
     return _LIB
@@ -188,6 +189,10 @@ class Context:
         """(form, unit_log2): 0 one lane per pixel (per-lane regeneration), 1 queue form, 2 item form (persistent waves, work counter)"""
         k = C.c_int32(0)
         return self.L.rt_debug_last_path_form(self.h, C.byref(k)), k.value
+
+    def last_whitted_form(self):
+        """1 wavefront form (walk / shadow rays / combine), 0 monolithic kernel"""
+        return self.L.rt_debug_last_whitted_form(self.h)
 
     def last_whitted_kernel(self):
         """2 scene-specialised (02 only), 1 generic"""

@@ -84,7 +84,8 @@ def test_02_first_primitive_casts_shadows(ctx):
     shadowed = (o_lit["rgb"].sum(axis=-1) - o["rgb"].sum(axis=-1)) > 0.2      # floor pixels the sphere darkens
     assert shadowed.sum() > 200
     imgs = {}
-    for name, flags in (("generic_lds", 8), ("generic_global", 8 | 64), ("specialised", 16)):
+    # 8 = no specialised kernel, 4096 = monolithic kernel (without it the generic 02 path is the wavefront form), 64 = shadow samples from global memory
+    for name, flags in (("generic_lds", 8 | 4096), ("generic_global", 8 | 64 | 4096), ("specialised", 16), ("wavefront_lds", 8), ("wavefront_global", 8 | 64)):
         ctx.set_debug_flags(flags)
         try:
             g = ctx.render_whitted(s, cam, prm, w, h)
@@ -97,6 +98,8 @@ def test_02_first_primitive_casts_shadows(ctx):
         imgs[name] = g["rgb"]
     assert np.array_equal(imgs["generic_lds"], imgs["specialised"])
     assert frac_within(imgs["generic_global"], imgs["generic_lds"], 1e-4) >= 0.998
+    assert frac_within(imgs["wavefront_lds"], imgs["specialised"], 2e-6, floor=1e-2) == 1.0      # same visibility counts, another summation order
+    assert frac_within(imgs["wavefront_global"], imgs["wavefront_lds"], 1e-4) >= 0.998
 
 
 def test_whitted_recursion_tree_both_branches(ctx):
@@ -456,7 +459,7 @@ def test_02_scene_specialised_kernel_matches_generic(ctx):
     """02's shadow samples (16 of its 17 rays per pixel) run generated code for small scenes, like the path kernels'
     scene query (rt_jit.hip): same arithmetic, so the same image bit for bit and the same ray counts; 01 never specialises."""
     s, cam, prm = scenes.scene02(16, seed=3)
-    ctx.set_debug_flags(8)
+    ctx.set_debug_flags(8 | 4096)      # the generic MONOLITHIC kernel (the generic default is the wavefront form: test_02_wavefront_form_...)
     try:
         a = ctx.render_whitted(s, cam, prm, 392, 280)
         assert ctx.last_whitted_kernel() == 1
@@ -802,3 +805,34 @@ def test_large_sphere_self_intersections_match_the_reference_arithmetic(ctx, rad
     assert len(rays) == 1                                       # generic, specialised and BVH kernels: the same paths
     assert abs(g["rays"] / o["rays"] - 1.0) <= 5e-4, g["rays"] / o["rays"] - 1.0
     assert abs(g["rgb"].mean() / (o["sum"] / 1024).mean() - 1.0) <= 5e-4
+
+
+@pytest.mark.parametrize("samples,size", [(16, (196, 140)), (1, (98, 70)), (5, (131, 77)), (64, (98, 70)), (256, (64, 48))])
+def test_02_wavefront_form_equals_the_monolithic_kernel(ctx, samples, size):
+    """The wavefront form of 02 (tree walk -> shadow requests in HBM -> 2^g threads per request -> per-pixel combine; debug flag
+    8192, and the default whenever no scene-specialised kernel exists) against the monolithic kernel (flag 4096): identical ray
+    counts, the same visibility counts (integer sums), colours equal to the rounding of a different summation order; generic
+    and scene-specialised builds of both; also on a scene whose recursion tree branches, with two lights (requests of deeper
+    tree nodes go through the atomic region, several requests per pixel are chained)."""
+    w, h = size
+    s, cam, prm = scenes.scene02(samples, seed=3)
+    branching = scenes.scene02(samples, seed=3)
+    bs = branching[0]
+    half = bs.phong((0.2, 0.3, 0.2), 0.8, 64.0, 0.3, 0.5, 0.7)      # reflects AND refracts
+    mirror = bs.phong((0.1, 0.1, 0.1), 1.0, 512.0, 0.25, 1.0)
+    bs.sphere(half, (-5, 2, -14), 2.5); bs.sphere(mirror, (6, -6, -13), 2.0); bs.light((6, 5, -6), (0.4, 0.4, 0.5), 1.5)
+    for scene, cam_, prm_ in ((s, cam, prm), (bs, branching[1], scenes.whitted_params(5, samples, 3))):
+        for build in (8, 16):
+            ctx.set_debug_flags(build | 8192); a = ctx.render_whitted(scene, cam_, prm_, w, h); fa = ctx.last_whitted_form()
+            ctx.set_debug_flags(build | 4096); b = ctx.render_whitted(scene, cam_, prm_, w, h); fb = ctx.last_whitted_form()
+            ctx.set_debug_flags(0)
+            assert (fa, fb) == (1, 0)
+            assert (a["rays"], a["shadow_rays"]) == (b["rays"], b["shadow_rays"])
+            assert frac_within(a["rgb"], b["rgb"], 1e-5, floor=1e-2) == 1.0      # measured: <= 3e-6 (a tree of several nodes and two lights summed in another order)
+            assert (a["bgra"] != b["bgra"]).mean() < 1e-4
+    # default policy: without a specialised kernel (first render of a fresh scene) the wavefront form, with one the monolithic kernel
+    fresh = scenes.scene02(samples, seed=3)[0]; fresh.sphere(0, (1.0 + 0.01 * samples, 2.0, -9.0), 0.7)
+    ctx.render_whitted(fresh, cam, prm, w, h); first = (ctx.last_whitted_form(), ctx.last_whitted_kernel())
+    ctx.render_whitted(fresh, cam, prm, w, h); second = (ctx.last_whitted_form(), ctx.last_whitted_kernel())
+    if os.environ.get("RT_MI355_JIT") is None:
+        assert first == (1, 1) and second == (0, 2), (first, second)
