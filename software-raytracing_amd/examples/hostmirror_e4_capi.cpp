@@ -89,3 +89,61 @@ extern "C" int hm_e4_triangle_hit(const float* v0, const float* v1, const float*
     if (hit) { out8[0] = h.t; out8[1] = h.point.x; out8[2] = h.point.y; out8[3] = h.point.z; out8[4] = h.normal.x; out8[5] = h.normal.y; out8[6] = h.normal.z; out8[7] = h.frontFaceSurface ? 1.0f : 0.0f; }
     return hit;
 }
+
+// ---- TraceTay on the host (host/04_PathTracingLights/TraceTay.hpp) ---------------------------------------------------------------
+namespace {
+bool build(const rt_scene* sc, scene::List* world) {
+    std::vector<std::shared_ptr<materials::Material>> mats;
+    for (int i = 0; i < sc->n_materials; ++i) {
+        const rt_material& m = sc->materials[i];
+        if (m.type == RT_MAT_DIFFUSE) mats.push_back(std::make_shared<materials::Diffuse>(v(m.albedo)));
+        else if (m.type == RT_MAT_METAL) mats.push_back(std::make_shared<materials::Metal>(v(m.albedo), m.roughness));
+        else if (m.type == RT_MAT_DIELECTRIC) mats.push_back(std::make_shared<materials::Refractive>(m.refraction_index));
+        else mats.push_back(std::make_shared<materials::Light>(v(m.albedo)));
+    }
+    for (int i = 0; i < sc->n_prims; ++i) {
+        const rt_prim& p = sc->prims[i]; const float* f = p.f;
+        const std::shared_ptr<materials::Material> m = p.material < 0 ? nullptr : mats[p.material];
+        const bool flip = (p.flags & RT_PRIM_FLAG_FLIP_NORMALS) != 0;
+        if (p.type == RT_PRIM_SPHERE) world->addElement(std::make_shared<scene::Sphere>(m, v(f), f[3], flip));
+        else if (p.type == RT_PRIM_PLANE) world->addElement(std::make_shared<scene::Plane>(m, v(f), v(f + 3)));
+        else if (p.type == RT_PRIM_RECT) world->addElement(std::make_shared<scene::Rectangle>(m, v(f), math::Vec2<float>(f[3], f[4]), v(f + 5)));
+        else if (p.type == RT_PRIM_BOX) world->addElement(std::make_shared<scene::Box>(m, v(f), v(f + 3), v(f + 6), flip));
+        else if (p.type == RT_PRIM_TRIANGLE) world->addElement(std::make_shared<scene::Triangle>(m, v(f), v(f + 3), v(f + 6)));
+        else return false;
+    }
+    return true;
+}
+}
+// one ray (direction normalised by the Ray constructor): out4 = colour, hit
+extern "C" int hm_e4_tracetay(const rt_scene* sc, const float* o, const float* d, unsigned depth, unsigned max_depth, float* out4) {
+    scene::List world; if (!build(sc, &world)) return 1;
+    TraceTayMaxDepth() = max_depth;
+    V3 c{-1.0f, -1.0f, -1.0f};
+    out4[3] = TraceTay(math::Ray(v(o), v(d)), world, &c, depth) ? 1.0f : 0.0f;
+    out4[0] = c.x; out4[1] = c.y; out4[2] = c.z;
+    TraceTayMaxDepth() = 6u;
+    return 0;
+}
+// the frame as the reference's Render samples it (Sources/04_PathTracingLights/Main.cpp:355-377): mean linear colour per pixel
+extern "C" int hm_e4_tracetay_frame(const rt_scene* sc, const rt_camera* cam, int w, int h, int spp, float* rgb) {
+    scene::List world; if (!build(sc, &world)) return 1;
+    const float fw = static_cast<float>(w), fh = static_cast<float>(h);
+    const float fovRadians = static_cast<float>(cam->fov_deg / (180.0f / M_PI));
+    const auto rot = math::GetRotationMat(v(cam->orientation_deg));
+    const unsigned samples = static_cast<unsigned>(spp);
+    for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
+        double acc[3] = {0, 0, 0};
+        for (unsigned s = 0; s < samples; ++s) {
+            const math::Vec2<float> bias = samples > 1 ? math::Vec2<float>(RndFloat(), RndFloat()) : math::Vec2<float>(0.5f, 0.5f);
+            const float x = (2.0f * (static_cast<float>(i) + bias.x) / fw - 1.0f) * tanf(fovRadians / 2.0f) * fw / fh;
+            const float y = -(2.0f * (static_cast<float>(j) + bias.y) / fh - 1.0f) * tanf(fovRadians / 2.0f);
+            V3 c{0.0f, 0.0f, 0.0f};
+            TraceTay(math::Ray(v(cam->position), rot * V3(x, y, -1.0f)), world, &c, 0);
+            acc[0] += c.x; acc[1] += c.y; acc[2] += c.z;
+        }
+        float* o = rgb + 3 * (static_cast<size_t>(j) * w + i);
+        for (int k = 0; k < 3; ++k) o[k] = static_cast<float>(acc[k] / samples);
+    }
+    return 0;
+}

@@ -4,6 +4,7 @@
 #include <memory>
 #include "Plane.hpp"
 #include "Sphere.hpp"
+#include "TraceTay.hpp"
 
 inline void Render(ImageBuffer<RGBQUAD>* imageBuffer, const float& fov, const std::vector<std::shared_ptr<SceneElement>>& sceneElements,
                    const std::vector<LightSource>& lightSources) {

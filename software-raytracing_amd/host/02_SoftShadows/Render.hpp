@@ -5,6 +5,7 @@
 #include <memory>
 #include "Plane.hpp"
 #include "Sphere.hpp"
+#include "TraceTay.hpp"
 
 inline uint32_t& RenderSeed() { static uint32_t seed = 1u; return seed; }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include "Materials.hpp"
 #include "Sphere.hpp"
+#include "TraceTay.hpp"
 
 inline uint32_t& RenderSeed() { static uint32_t seed = 1u; return seed; }
 

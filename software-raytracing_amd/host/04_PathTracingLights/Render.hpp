@@ -10,6 +10,7 @@
 #include "Scene/Rectangle.hpp"
 #include "Scene/Sphere.hpp"
 #include "Scene/Triangle.hpp"
+#include "TraceTay.hpp"
 
 inline uint32_t& RenderSeed() { static uint32_t seed = 1u; return seed; }
 

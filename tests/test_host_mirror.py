@@ -344,3 +344,112 @@ def test_example_bvh_flag_gives_the_same_frame(example, tmp_path):
     subprocess.run(base + ["--out", a], check=True, capture_output=True, timeout=120)
     subprocess.run(base + ["--bvh", "--out", b], check=True, capture_output=True, timeout=120)
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+# ---- TraceTay on the host: the reference's secondary seam (host/0N/TraceTay.hpp; no GPU) ---------------------------------
+def _shim(n):
+    L = C.CDLL(_need(os.path.join(BIN, f"libhostmirror_e{n}.so")))
+    if n <= 2:
+        f = getattr(L, f"hm_e{n}_tracetay_frame")
+        f.argtypes = [C.POINTER(abi.rt_scene), C.c_float, C.c_int, C.c_int, FP]
+    else:
+        getattr(L, f"hm_e{n}_tracetay").argtypes = [C.POINTER(abi.rt_scene), FP, FP, C.c_uint, C.c_uint, FP]
+        getattr(L, f"hm_e{n}_tracetay_frame").argtypes = [C.POINTER(abi.rt_scene), C.POINTER(abi.rt_camera), C.c_int, C.c_int, C.c_int, FP]
+    return L
+
+
+def test_host_tracetay_01_is_the_reference_frame_bit_for_bit():
+    """TraceTay of 01 (01 Main.cpp:372-496) through the host classes, pixel loop as the reference's Render: every float of the
+    196x140 frame computed by the reference's own classes (tests/golden/frame_01.npz)."""
+    L = _shim(1)
+    k = np.load(os.path.join(GOLDEN, "frame_01.npz"))
+    sc, cam, prm = scenes.scene01()
+    rgb = np.zeros((140, 196, 3), np.float32)
+    assert L.hm_e1_tracetay_frame(C.byref(sc.c()), 90.0, 196, 140, fp(rgb)) == 0
+    assert same(rgb, k["rgb196"])
+    L.hm_e1_set_max_depth(0)                       # the depth limit is a setting here: primary hits shade, their children see the sky
+    shallow = np.zeros_like(rgb)
+    L.hm_e1_tracetay_frame(C.byref(sc.c()), 90.0, 196, 140, fp(shallow))
+    L.hm_e1_set_max_depth(4)
+    assert not same(shallow, rgb) and same(shallow[0, 0], rgb[0, 0])      # matte walls do not recurse
+
+
+def test_host_tracetay_02_converges_to_the_reference_image():
+    """TraceTay + RandomVectorToLightSphere of 02 (02 Main.cpp:389-566): the mean of 24 evaluations of the 16-sample frame against
+    the mean of 512 evaluations by the reference's own code, SURVEY 8(c) bound; the light vectors are unit and inside the disk's cone."""
+    from test_converged_goldens import _check
+    L = _shim(2)
+    L.hm_e2_settings.argtypes = [C.c_uint, C.c_uint]
+    L.hm_e2_light_vectors.argtypes = [FP, FP, C.c_float, C.c_int, FP]
+    sc, cam, prm = scenes.scene02(16)
+    n = 24
+    L.hm_e2_settings(16, 12345)
+    acc = np.zeros((140, 196, 3), np.float64); rgb = np.zeros((140, 196, 3), np.float32)
+    for _ in range(n):
+        assert L.hm_e2_tracetay_frame(C.byref(sc.c()), 90.0, 196, 140, fp(rgb)) == 0
+        acc += rgb
+    _check("host TraceTay 02", acc / n, n, "02", gamma=False)
+    pt = np.array([1.0, -10.0, -12.0], np.float32); lp = np.array([0.0, 6.5, -10.0], np.float32)
+    d = np.zeros((4000, 3), np.float32)
+    L.hm_e2_light_vectors(fp(pt), fp(lp), 3.0, 4000, fp(d))
+    assert np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-6
+    to = (lp - pt) / np.linalg.norm(lp - pt)
+    dist = np.linalg.norm(lp - pt)
+    off = np.tan(np.arccos(np.clip(d @ to, -1, 1))) * dist                # distance from the disk's centre, in the disk's plane
+    assert off.max() <= 3.0 * 1.001 and 1.3 < off.mean() < 1.7            # radius linear in one uniform: mean r/2 (centre-heavy), as written
+
+
+@pytest.mark.parametrize("example,which,spp", [(3, "03", 48), (4, "04", 48)])
+def test_host_tracetay_path_converges_to_the_reference_image(example, which, spp):
+    """TraceTay of 03 / 04 (03 Main.cpp:380-435, 04 Main.cpp:431-502) over the host classes' intersectsRay / scatter /
+    scatteredRay, sampled as the reference's Render samples a frame: against the converged image rendered by the reference's own
+    code (tests/golden/converged_0{3,4}.npz), SURVEY 8(c) bound."""
+    from test_converged_goldens import _check
+    L = _shim(example)
+    sc, cam, prm = scenes.scene03(spp) if example == 3 else scenes.scene04(spp)
+    rgb = np.zeros((140, 196, 3), np.float32)
+    assert getattr(L, f"hm_e{example}_tracetay_frame")(C.byref(sc.c()), C.byref(cam), 196, 140, spp, fp(rgb)) == 0
+    _check(f"host TraceTay {which}", rgb, spp, which)
+
+
+def test_host_tracetay_path_deterministic_chains():
+    """What does not depend on the clock-seeded engines, value for value: 03's sky (the double-precision ratio of Main.cpp:430),
+    black beyond the depth limit, an element without material, a roughness-0 metal chain; 04's black background, a light seen
+    from the front (emitted colour) and from behind (black), the depth limit."""
+    L3, L4 = _shim(3), _shim(4)
+    out = np.zeros(4, np.float32)
+    f32 = np.float32
+    # 03: a miss
+    s = scenes.Scene(); m = s.metal((0.8, 0.6, 0.2), 0.0); s.sphere(m, (0, 0, -3), 1.0); s.sphere(-1, (4, 0, -3), 1.0)
+    o = np.zeros(3, np.float32)
+    d = np.array([0.0, 1.0, -0.2], np.float32)
+    L3.hm_e3_tracetay(C.byref(s.c()), fp(o), fp(d), 0, 24, fp(out))
+    ln = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); dy = f32(d[1] / ln)
+    h = f32(0.5 * (float(dy) + 1.0))
+    sky = lambda hh: np.array([f32(1) + f32(f32(0.5) - f32(1)) * hh, f32(1) + f32(f32(0.7) - f32(1)) * hh, f32(1) + f32(f32(1) - f32(1)) * hh], np.float32)
+    assert out[3] == 0 and same(out[:3], sky(h))
+    # beyond the depth limit: black, no hit
+    L3.hm_e3_tracetay(C.byref(s.c()), fp(o), fp(d), 3, 2, fp(out))
+    assert list(out) == [0, 0, 0, 0]
+    # an element without material: a hit, black
+    L3.hm_e3_tracetay(C.byref(s.c()), fp(np.array([4, 0, 0], np.float32)), fp(np.array([0, 0, -1], np.float32)), 0, 24, fp(out))
+    assert list(out) == [0, 0, 0, 1]
+    # mirror metal straight on: reflected back along +z into the sky, attenuated by the albedo
+    L3.hm_e3_tracetay(C.byref(s.c()), fp(o), fp(np.array([0, 0, -1], np.float32)), 0, 24, fp(out))
+    assert out[3] == 1 and np.allclose(out[:3], np.array([0.8, 0.6, 0.2]) * sky(f32(0.5)), rtol=1e-6)
+    # ... and black when the child would exceed the limit
+    L3.hm_e3_tracetay(C.byref(s.c()), fp(o), fp(np.array([0, 0, -1], np.float32)), 0, 0, fp(out))
+    assert list(out) == [0, 0, 0, 1]
+    # 04
+    s = scenes.Scene(); lm = s.light_material((15, 14, 13)); s.rect(lm, (0, 4.95, 0), (3, 3), (90, 0, 0)); s.sphere(-1, (6, 0, 0), 1.0)
+    up, down = np.array([0, 1, 0], np.float32), np.array([0, -1, 0], np.float32)
+    L4.hm_e4_tracetay(C.byref(s.c()), fp(np.zeros(3, np.float32)), fp(up), 0, 6, fp(out))
+    assert list(out) == [15, 14, 13, 1]                                                # seen from the front
+    L4.hm_e4_tracetay(C.byref(s.c()), fp(np.array([0, 8, 0], np.float32)), fp(down), 0, 6, fp(out))
+    assert list(out) == [0, 0, 0, 1]                                                   # from behind: a hit that emits nothing
+    L4.hm_e4_tracetay(C.byref(s.c()), fp(np.zeros(3, np.float32)), fp(down), 0, 6, fp(out))
+    assert list(out) == [0, 0, 0, 0]                                                   # background
+    L4.hm_e4_tracetay(C.byref(s.c()), fp(np.zeros(3, np.float32)), fp(up), 7, 6, fp(out))
+    assert list(out) == [0, 0, 0, 0]                                                   # beyond the limit
+    L4.hm_e4_tracetay(C.byref(s.c()), fp(np.zeros(3, np.float32)), fp(np.array([1, 0, 0], np.float32)), 0, 6, fp(out))
+    assert list(out) == [0, 0, 0, 1]                                                   # no material
