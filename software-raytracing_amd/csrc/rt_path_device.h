@@ -99,7 +99,14 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
         const uint32_t moff = mats0 + __float_as_uint(sb.w);
         float4 m0 = M.ld4(moff), m2 = M.ld4(moff + 32U);
         int mtype = __float_as_int(m0.w);
-        if (mtype == MAT_DIFFUSE || mtype == MAT_METAL || mtype == MAT_DIELECTRIC) {
+        const bool scatters = mtype == MAT_DIFFUSE || mtype == MAT_METAL || mtype == MAT_DIELECTRIC;
+        if (scatters && L.depth >= A.max_depth) {
+            // the scattered ray would be traced beyond the depth limit, i.e. return black (03 Main.cpp:383-386, 04 Main.cpp:438-441), and a
+            // scattering material adds nothing of its own: the path ends here, without the sampling.  In a closed scene nearly every
+            // path runs to the limit and a wave's lanes reach it together (measured on 04: 63.5 of 64 lanes regenerate in the same
+            // iteration), so every (max_depth + 1)-th iteration of a wave skips the whole scatter code.
+            L.alive = false;
+        } else if (scatters) {
             // one draw per bounce serves whichever material was hit: (fi, theta) halves for the hemisphere/cone
             // samplers, the top 24 bits for the dielectric's reflect-or-refract choice
             const uint32_t r = lowbias32(L.rkey);      // = rng_bits(L.skey, 4*(depth+1))
@@ -168,7 +175,6 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
             if (VARIANT == 4 && mtype == MAT_LIGHT && !back) add_radiance<DEPOSIT>(L, L.thr * F3(m0));   // Light.hpp:47-54, Main.cpp:480-483
             L.alive = false;
         }
-        if (L.depth > A.max_depth) L.alive = false;   // 03 Main.cpp:383-386, 04 Main.cpp:438-441
     }
 }
 
@@ -266,6 +272,8 @@ __device__ __forceinline__ void path_items_body(const DevScene& SD, const PathAr
     const int k = A.unit_log2, P = 1 << k;
     const uint32_t n_pixels = (uint32_t)A.width * (uint32_t)A.height;
     unsigned int rays = 0;
+    unsigned int stat = 0;      // experiments (RT_MI355_JIT_DEFS=RT_STAT_ITER | RT_STAT_PASS): a wave-level event count, reported in the shadow-ray counter (tools/pool_stats.py)
+    (void)stat;
 
     for (;;) {
         // ---- next unit of work: one atomic per wave and unit
@@ -300,7 +308,13 @@ __device__ __forceinline__ void path_items_body(const DevScene& SD, const PathAr
             const bool left = next < n_items;
             if (m_alive == 0ULL && !left) break;
             const unsigned long long m_idle = ~m_alive;
+#ifdef RT_STAT_ITER
+            ++stat;
+#endif
             if (left && (m_alive == 0ULL || __popcll(m_idle) >= A.regen_threshold)) {
+#ifdef RT_STAT_PASS
+                ++stat;
+#endif
                 // idle lanes take the next items in lane order: (pixel, sample) = (item mod P, item div P)
                 const uint32_t item = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0U));
                 next += (uint32_t)__popcll(m_idle);
@@ -351,6 +365,9 @@ __device__ __forceinline__ void path_items_body(const DevScene& SD, const PathAr
         __builtin_amdgcn_wave_barrier();
     }
     wave_add_u64(counters + 2 * ((blockIdx.x * 4 + wave) % RT_COUNTER_BANKS), rays);
+#if defined(RT_STAT_ITER) || defined(RT_STAT_PASS)
+    if (lane == 0) atomicAdd(counters + 2 * ((blockIdx.x * 4 + wave) % RT_COUNTER_BANKS) + 1, (unsigned long long)stat);
+#endif
 }
 
 // =================================================================================================
