@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_path_q(DevScene SD, PathArgs A, float4*
 
 // Item form (rt_path_device.h): persistent waves pulling (pixel group x sample slice) units from a work counter.
 template <int VARIANT, bool LDS, bool EARLY = false>
-__global__ __launch_bounds__(256) void k_path_items(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_path_items(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     path_items_body<VARIANT, LDS, EARLY>(SD, A, out, counters);
 }
 

@@ -16,7 +16,7 @@ for name in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_flops"):
     agg = collections.defaultdict(float); launches = set()
     for f in glob.glob(os.path.join(src, name, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if "k_path" in r["Kernel_Name"] and int(r["Grid_Size"]) > 1000000:   # the bench frame, not the 16x16 setup render
+            if "k_path" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 200000:   # the bench frame (item form: a persistent grid of 8 blocks per CU), not the 16x16 setup render
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); launches.add(r["Dispatch_Id"])
     passes[name] = dict(agg); passes[name + "_launches"] = len(launches)
 b = json.loads(line(os.path.join(src, "pmc_sq.json")))
