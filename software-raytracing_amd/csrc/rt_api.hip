@@ -671,18 +671,21 @@ int pick_slices(int width, int height, int n_samples) {
     return s < 1 ? 1 : s;
 }
 // Item form (path_items_body): a unit of work is 2^unit_log2 consecutive pixels x the sample range.  Long frames are cut into
-// units by shrinking the PIXEL group, not the sample range - at most RT_UNIT_ITEMS paths per unit whatever the frame (16 pixels
-// at 1024 spp, 64 at <= 256) - so every pixel keeps one owner and no partial image exists.  A wave drains a unit before it takes
-// the next (its last paths run in a partly filled wave), so a unit must be long against one path - at least RT_UNIT_MIN_ITEMS,
-// 64 paths per lane - and there must be enough units to occupy the chip; frames too small for both (784x561 at 32 spp is 0.5 ms of
-// work) keep one lane per pixel and sample slices (path_body), which fill the chip with fewer paths per wave.
-constexpr int RT_UNIT_ITEMS = 16384, RT_UNIT_MIN_ITEMS = 4096;
+// units by shrinking the PIXEL group, not the sample range - at most RT_UNIT_ITEMS paths per unit whatever the frame (4 pixels
+// at 1024 spp, 16 at 256, 64 at <= 64) - so every pixel keeps one owner and no partial image exists.  The unit size is a
+// measured compromise (tools/sweep_unit.py, profiles/r03_unit_size_sweep.txt): a wave drains a unit before it takes the next (its
+// last paths run in a partly filled wave: short units cost 03 +5 % at 2048 paths, nothing on 04, whose paths end together), few
+// pixels per unit put many lanes on one pixel's sums (same-address LDS atomics: 03 x2 at 2 pixels), and long units make the
+// launch's tail long and its load uneven (03 at 1080p/256 spp: 6.0 ms at 16384 paths per unit, 5.4 at 4096).  There must also
+// be enough units to occupy the chip; frames too small for that (784x561 at 32 spp is 0.5 ms of work) keep one lane per pixel
+// and sample slices (path_body), which fill the chip with fewer paths per wave.
+constexpr int RT_UNIT_ITEMS = 4096, RT_UNIT_MIN_ITEMS = 2048;
 struct ItemPlan { bool ok; int unit_log2, n_groups; };
 ItemPlan plan_items(int width, int height, int n_samples, int n_cus) {
     const long long pixels = (long long)width * height, waves = (long long)n_cus * 32;      // resident waves at 8 blocks per CU
     int k = 6;
     while (k > 0 && ((long long)n_samples << k) > RT_UNIT_ITEMS) --k;
-    while (k > 0 && (pixels >> k) < 2 * waves && ((long long)n_samples << (k - 1)) >= RT_UNIT_MIN_ITEMS) --k;
+    while (k > 0 && (pixels >> k) < 6 * waves && ((long long)n_samples << (k - 1)) >= RT_UNIT_MIN_ITEMS) --k;      // small frames: more, shorter units (784x561 at 256 spp: 3.5 -> 3.3 ms)
     ItemPlan p{true, k, (int)((pixels + (1 << k) - 1) >> k)};
     p.ok = ((long long)n_samples << k) >= RT_UNIT_MIN_ITEMS && p.n_groups >= waves;
     return p;
@@ -968,6 +971,13 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
         }
         if (c->debug_flags & 1024) ip.ok = true;                 // tests: item form on small frames too
         A.items = ip.ok ? 1 : 0; A.unit_log2 = ip.unit_log2; A.n_groups = ip.n_groups;
+        // Units are handed out BOTTOM-UP (last pixel group first).  The launch ends when the last unit does, so cheap units should
+        // come last; what a unit costs is not known beforehand, but a camera that looks at the horizon has the sky on top (one ray
+        // per sample) and the ground below (03: 3 rays per sample), and a closed room does not care.  Measured (tools/sweep_order.py,
+        // profiles/r03_unit_size_sweep.txt): 03 1080p/256 spp 5.57 -> 5.37 ms, 04 within +-0.5 %; a strided order was no better.
+        // RT_MI355_UNIT_ORDER=0: row-major (experiment switch).
+        A.unit_order = 1;
+        if (const char* e = getenv("RT_MI355_UNIT_ORDER")) A.unit_order = atoi(e) == 0 ? 0 : 1;
     }
     if (!A.items && !A.sorted && n_samples > 0) slices = pick_slices(width, height, n_samples);
     if (const char* e = getenv("RT_MI355_SLICES")) {      // experiment switch: sample slices per frame

@@ -36,6 +36,7 @@ struct PathArgs {
     // pixel groups per slice, n_units = n_groups x slices units in all, handed out through counters[RT_WORK_COUNTER]
     int items, unit_log2, n_groups, n_units;
     int sorted;                     // the outcome-sorted form (path_sorted_body): units belong to workgroups
+    int unit_order;                 // item form: order in which the pixel groups are handed out: 0 row-major, 1 bottom-up (last group first)
     uint32_t seed;
     float t_min, t_min_pos, t_max;  // t_min_pos = max(t_min, smallest positive float): "t > 0 && t >= tMin" in one compare
     float inv_w2, inv_h2, kx, ky;   // 2/w, 2/h, tan(fov/2)*w/h, tan(fov/2)

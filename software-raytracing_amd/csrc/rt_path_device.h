@@ -283,6 +283,7 @@ __device__ __forceinline__ void path_items_body(const DevScene& SD, const PathAr
         if (u >= (uint32_t)A.n_units) break;
         uint32_t slice = 0U, group = u;
         if (A.n_units != A.n_groups) { slice = u / (uint32_t)A.n_groups; group = u - slice * (uint32_t)A.n_groups; }
+        if (A.unit_order == 1) group = (uint32_t)A.n_groups - 1U - group;      // bottom-up: the launch ends with the cheap units of a frame that has sky on top (rt_api.hip)
         const int s_first = A.sample_begin + (int)slice * A.slice_len;
         const int s_end = min(s_first + A.slice_len, A.sample_end);
         const uint32_t first_px = group << k;                                  // the group's pixels: first_px .. first_px + P - 1, row-major
