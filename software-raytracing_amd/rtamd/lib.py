@@ -19,20 +19,30 @@ class RtError(RuntimeError):
         self.code = code
 
 
-SYSTEM_COMGR = "/opt/rocm/lib/libamd_comgr.so.3"
+COMGR_SONAME_MAJOR = 3       # libamd_comgr.so.3: the ABI the HIP runtime PyTorch bundles was linked against
+SYSTEM_COMGR = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", f"libamd_comgr.so.{COMGR_SONAME_MAJOR}")
 
 
 def prefer_system_compiler():
     """Call BEFORE `import torch`.  The scene-specialised kernels are compiled at run time through hiprtc -> libamd_comgr of
     whichever ROCm runtime the process loaded first; PyTorch bundles an older one (ROCm 7.0) than the image ships (7.2), and the
     older compiler's kernel is 3 % slower (tools/runtime_probe.py).  Loading the system's compiler library first, with global
-    visibility, makes it the provider of amd_comgr_* for the whole process (same soname, same ABI).  A host that never imports
-    torch gets the system compiler anyway.  -> a description of the compiler in use."""
+    visibility, makes it the provider of amd_comgr_* for the whole process (same soname, same ABI).  It is only taken when it
+    reports the soname's major version through amd_comgr_get_version (an ABI check, not a bet on the file name); otherwise, and
+    with RT_MI355_SYSTEM_COMGR=0, the process keeps whatever compiler its HIP runtime brings (the GPU suite passes either way:
+    tests/test_gpu_bundled_compiler.py).  A host that never imports torch gets the system compiler anyway.
+    -> a description of the compiler in use."""
     if os.environ.get("RT_MI355_SYSTEM_COMGR", "1") != "0" and "torch" not in sys.modules:
         try:
+            probe = C.CDLL(SYSTEM_COMGR)          # local first: nothing binds to it unless the version check passes
+            major, minor = C.c_size_t(0), C.c_size_t(0)
+            probe.amd_comgr_get_version.restype = None
+            probe.amd_comgr_get_version(C.byref(major), C.byref(minor))
+            if major.value != COMGR_SONAME_MAJOR:
+                return f"the ROCm runtime the process loads ({SYSTEM_COMGR} reports comgr {major.value}.{minor.value}, not {COMGR_SONAME_MAJOR}.x: not used)"
             C.CDLL(SYSTEM_COMGR, mode=C.RTLD_GLOBAL)
-            return SYSTEM_COMGR + " (loaded before torch)"
-        except OSError:
+            return f"{SYSTEM_COMGR} (comgr {major.value}.{minor.value}, loaded before torch)"
+        except (OSError, AttributeError):
             pass
     return "the ROCm runtime bundled with PyTorch" if "torch" in sys.modules else "the first ROCm runtime the process loads"
 

@@ -1,0 +1,25 @@
+"""The scene-specialised kernels under the OTHER compiler: conftest.py makes every test of this suite compile them with the image's
+libamd_comgr (as bench.py does); a host that simply imports torch first gets the older one PyTorch bundles.  One child process does that and checks
+the property the specialised kernels stand on - the same image as the generic kernel, bit for bit, and the same ray counts - for 02, 03 and 04."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.gpu
+def test_specialised_kernels_match_generic_under_the_bundled_compiler(ctx):
+    env = dict(os.environ, RT_MI355_SYSTEM_COMGR="0")
+    env.pop("RT_MI355_JIT", None)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "bundled_compiler_child.py")], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "PyTorch" in out["compiler"], out["compiler"]
+    for name, c in out["cases"].items():
+        assert c["kernels"] == ([1, 2] if name == "02" else [2, 1]), (name, c)               # 03/04: specialised, then generic; 02: generic, then specialised
+        assert c["rays"][0] == c["rays"][1] and c["rgb_equal"], (name, c)
+        assert c["mean"] > 0.01
