@@ -671,8 +671,8 @@ int pick_slices(int width, int height, int n_samples) {
     return s < 1 ? 1 : s;
 }
 // Item form (path_items_body): a unit of work is 2^unit_log2 consecutive pixels x the sample range.  Long frames are cut into
-// units by shrinking the PIXEL group, not the sample range - at most RT_UNIT_ITEMS paths per unit whatever the frame (4 pixels
-// at 1024 spp, 16 at 256, 64 at <= 64) - so every pixel keeps one owner and no partial image exists.  The unit size is a
+// units by shrinking the PIXEL group, not the sample range - about RT_UNIT_ITEMS paths per unit whatever the frame (16 pixels
+// at 256 ... 1024 spp, 64 at <= 64) - so every pixel keeps one owner and no partial image exists.  The unit size is a
 // measured compromise (tools/sweep_unit.py, profiles/r03_unit_size_sweep.txt): a wave drains a unit before it takes the next (its
 // last paths run in a partly filled wave: short units cost 03 +5 % at 2048 paths, nothing on 04, whose paths end together), few
 // pixels per unit put many lanes on one pixel's sums (same-address LDS atomics: 03 x2 at 2 pixels), and long units make the
@@ -685,6 +685,9 @@ ItemPlan plan_items(int width, int height, int n_samples, int n_cus) {
     const long long pixels = (long long)width * height, waves = (long long)n_cus * 32;      // resident waves at 8 blocks per CU
     int k = 6;
     while (k > 0 && ((long long)n_samples << k) > RT_UNIT_ITEMS) --k;
+    // a unit's pixels are stored as one run of 16 B x 2^k: two 128-byte lines when that keeps the unit within 4 x RT_UNIT_ITEMS (measured HBM writes per 4K frame
+    // of 132.7 MB at 1024 spp: 4 pixels per unit 199.5 MB - partial lines -, 8 pixels 166.3 MB, 16 pixels 149.8 MB; same speed, 04's paths end together)
+    while (k < 4 && ((long long)n_samples << (k + 1)) <= 4 * RT_UNIT_ITEMS) ++k;
     while (k > 0 && (pixels >> k) < 6 * waves && ((long long)n_samples << (k - 1)) >= RT_UNIT_MIN_ITEMS) --k;      // small frames: more, shorter units (784x561 at 256 spp: 3.5 -> 3.3 ms)
     ItemPlan p{true, k, (int)((pixels + (1 << k) - 1) >> k)};
     p.ok = ((long long)n_samples << k) >= RT_UNIT_MIN_ITEMS && p.n_groups >= waves;
