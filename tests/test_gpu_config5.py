@@ -111,3 +111,25 @@ def test_full_size_config5_4k_4096spp_properties(ctx, oracle_small):
         assert torch.allclose(q[0] + q[1], q[2], rtol=1e-5, atol=1e-5)
     finally:
         ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_NONE)
+
+
+def test_brute_force_at_the_stated_frame_equals_the_bvh_walk_on_a_sample_range(ctx):
+    """The brute-force kernel (the reference's algorithm, what the config-5 roofline figure is quoted on) at the FULL 3840x2160 frame, on samples
+    [3000, 3002) of the 4096: bit for bit the accumulators and the ray count of the BVH walk on the same range - so the full-size property test above,
+    which runs through the BVH for time's sake, speaks for the brute-force frame too (its full run is a 12.5-minute measurement: tools/run_config5.py,
+    profiles/r03_config5_bruteforce_run_{a,b}.log)."""
+    import torch
+    w, h, spp = 3840, 2160, 4096
+    s, cam, _ = scenes.scene_stress(spp=spp, seed=1)
+    p = scenes.path_params(abi.RT_PATH_LIGHTS, spp, max_depth=8, seed=1, sample_begin=3000, sample_end=3002)
+    a = torch.zeros(h * w * 4, dtype=torch.float32, device="cuda"); b = torch.zeros_like(a)
+    ctx.path_accumulate_device(s, cam, p, w, h, a.data_ptr()); ra = ctx.sync()["rays"]
+    assert ctx.last_path_kernel()[0] == 0                      # LDS-tiled brute force
+    ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_BVH)
+    try:
+        ctx.path_accumulate_device(s, cam, p, w, h, b.data_ptr()); rb = ctx.sync()["rays"]
+        assert ctx.last_path_kernel()[0] == 3
+    finally:
+        ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_NONE)
+    assert ra == rb and bool(torch.equal(a, b))
+    assert bool((a.view(h, w, 4)[:, :, 3] == 2).all()) and abs(ra / (w * h * 2) - 4.582) < 0.02      # rays per sample of the full run: 4.5822
