@@ -1056,10 +1056,12 @@ int32_t rt_whitted_device(rt_ctx* c, const rt_scene* scene, const rt_camera* cam
     hipFunction_t jit = nullptr, jit_stage2 = nullptr;
     const char* jit_env = getenv("RT_MI355_JIT");
     c->jit_note.clear();
-    if (p->shadow_samples > 0 && !(c->debug_flags & 8) && !(jit_env && jit_env[0] == '0') &&
-        jit_wanted(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, (double)width * height * p->shadow_samples * (scene->n_lights > 0 ? scene->n_lights : 1),
+    // 01 (round 3): the same for its strict queries - every ray of the tree walk and its one shadow ray per hit and light (02's tree walk too)
+    const int jit_variant = p->shadow_samples > 0 ? RT_JIT_WHITTED_SOFT : RT_JIT_WHITTED_HARD;
+    if (!(c->debug_flags & 8) && !(jit_env && jit_env[0] == '0') &&
+        jit_wanted(jit_variant, H.slots, H.sruns, (double)width * height * (p->shadow_samples > 0 ? p->shadow_samples : 1) * (scene->n_lights > 0 ? scene->n_lights : 1),
                    (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
-        jit = jit_path_kernel(RT_JIT_WHITTED_SOFT, H.slots, H.sruns, 0.01f, 1000.0f, RT_FORM_REGEN, c->jit_note, &jit_stage2);
+        jit = jit_path_kernel(jit_variant, H.slots, H.sruns, 0.01f, 1000.0f, RT_FORM_REGEN, c->jit_note, &jit_stage2, &H.runs, &H.geom);
     c->last_whitted_kernel = jit ? 2 : 1;
     // Wavefront form (rt_whitted_device.h; debug flag 8192 or RT_MI355_WHITTED=w): the tree walk emits shadow REQUESTS, a second
     // kernel traces them with 2^g threads per request, a third adds their contributions per pixel.  Request slots: one per (pixel,
@@ -1313,14 +1315,16 @@ int32_t rt_debug_last_whitted_form(const rt_ctx* c) { return c ? c->last_whitted
 // which form of the bounce loop rendered the last path image: 0 per-lane regeneration (one lane per pixel), 1 queue form, 2 item
 // form (persistent waves + work counter); unit_log2: item form, log2 of the pixels per unit of work
 int32_t rt_debug_last_path_form(const rt_ctx* c, int32_t* unit_log2) { if (!c) return -1; if (unit_log2) *unit_log2 = c->last_unit_log2; return c->last_path_form; }
-// variant 3 / 4: the path kernels; 2: the 02 kernel (a Whitted scene)
+// variant 3 / 4: the path kernels; 2: the 02 kernel, 1: the 01 kernel (a Whitted scene)
 int32_t rt_debug_jit_probe(const rt_scene* scene, int32_t variant, char* note, int32_t cap) {
     HostScene H;
     const float tmin = (variant & 7) == 3 ? 0.001f : 0.01f;       // the examples' constants (rt_path_params_default)
-    int rc = compile_scene(nullptr, scene, (variant & 7) == RT_JIT_WHITTED_SOFT ? 0 : (variant & 7), tmin, H);
+    const bool whitted = (variant & 7) == RT_JIT_WHITTED_SOFT || (variant & 7) == RT_JIT_WHITTED_HARD;
+    int rc = compile_scene(nullptr, scene, whitted ? 0 : (variant & 7), tmin, H);
     if (rc) return rc;
     std::string n;
-    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, tmin, 1000.0f, (variant & 8) ? RT_FORM_QUEUE : (variant & 16) ? RT_FORM_ITEMS : (variant & 32) ? RT_FORM_SORTED : RT_FORM_REGEN, n);
+    hipFunction_t fn = jit_path_kernel(variant & 7, H.slots, H.sruns, tmin, 1000.0f, (variant & 8) ? RT_FORM_QUEUE : (variant & 16) ? RT_FORM_ITEMS : (variant & 32) ? RT_FORM_SORTED : RT_FORM_REGEN, n,
+                                       nullptr, whitted ? &H.runs : nullptr, whitted ? &H.geom : nullptr);
     if (note && cap > 0) { strncpy(note, n.c_str(), (size_t)cap - 1); note[cap - 1] = 0; }
     return fn ? 1 : 0;
 }

@@ -158,6 +158,38 @@ std::string gen_any_hit(const std::vector<float4>& slots, const std::vector<int4
 }
 
 
+// ---- the Whitted kernels' strict queries (01: every ray; 02: the tree walk) ----------------------------------------------
+// strict::closest_hit / strict::any_hit (rt_strict.h) walk the run table and read every primitive through scalar loads from global
+// memory: per run a dependent load, per primitive another - on a 784x561 frame (less than one wave per SIMD slot) that latency IS the
+// frame time.  Generated: one call of the same strict test per primitive, in scene order, its numbers as literals - the operations
+// the reference's x86 build executes, bit for bit (the tests are the inline functions of rt_strict.h, compiled under its
+// 'fp contract(off)'; constant folding of literal-only subexpressions rounds like the hardware does).  That this holds was NOT
+// free: with -ffp-contract=fast the backend fuses multiply-add pairs whatever the pragma says, and literal operands changed
+// which ones it picked - the specialised 01 frame differed from the generic one in 681 pixels until both builds moved to
+// -ffp-contract=fast-honor-pragmas (Makefile; options below).  RT_MI355_JIT_NO_STRICT=1 keeps the run-table walk (A/B switch).
+std::string f4lit(const float4& g) { return "make_float4(" + lit(g.x) + ", " + lit(g.y) + ", " + lit(g.z) + ", " + lit(g.w) + ")"; }
+std::string gen_strict_queries(const std::vector<int4>& wruns, const std::vector<float4>& wgeom) {
+    std::string c = "namespace rt {\n__device__ __forceinline__ int closest_hit_strict_jit(f3 o, f3 d, float tmin, float tmax, float& t_out) {\n    int best = -1;\n    float nearest = 3.402823466e+38f;\n";
+    std::string a = "__device__ __forceinline__ bool any_hit_strict_jit(f3 o, f3 d, float tmin, float tmax) {\n    bool hit = false;\n";
+    for (const int4& run : wruns) {
+        const float4* g = wgeom.data() + run.y;
+        for (int i = 0; i < run.z; ++i) {
+            std::string call, pre;
+            if (run.x == PRIM_SPHERE) call = "strict::hit_sphere(" + f4lit(g[i]) + ", o, d, tmin, tmax, t)";
+            else if (run.x == PRIM_PLANE) call = "strict::hit_plane(" + v3(g[2 * i]) + ", " + v3(g[2 * i + 1]) + ", o, d, tmin, tmax, t)";
+            else if (run.x == PRIM_TRI) {
+                pre = "const float4 g4[4] = {" + f4lit(g[4 * i]) + ", " + f4lit(g[4 * i + 1]) + ", " + f4lit(g[4 * i + 2]) + ", " + f4lit(g[4 * i + 3]) + "}; ";
+                call = "strict::hit_tri(g4, o, d, tmin, tmax, t)";
+            } else continue;
+            c += "    { " + pre + "float t; if (" + call + " && t < nearest) { nearest = t; best = " + std::to_string(run.w + i) + "; } }\n";
+            a += "    { " + pre + "float t; hit |= " + call + "; }\n";
+        }
+    }
+    c += "    t_out = nearest;\n    return best;\n}\n";
+    a += "    return hit;\n}\n} // namespace rt\n";
+    return c + a;
+}
+
 // ---- generation 2 of the generated scene query ("key" form) ------------------------------------------------------------
 // What the first generation spent most of its non-arithmetic instructions on is the bookkeeping per primitive: two float
 // compares (t >= tMin, t <= closest; 4.6 issue cycles each on gfx950, twice a VOP2), a scalar AND and two selects.  Here
@@ -288,10 +320,14 @@ bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector
     return false;
 }
 
-hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note, hipFunction_t* second) {
+hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note, hipFunction_t* second,
+                              const std::vector<int4>* wruns, const std::vector<float4>* wgeom) {
     if (second) *second = nullptr;
+    const bool whitted = variant == RT_JIT_WHITTED_SOFT || variant == RT_JIT_WHITTED_HARD;
     size_t n_prims = 0;
     for (const int4& r : sruns) n_prims += (size_t)r.z;
+    if (whitted && wruns) { size_t n = 0; for (const int4& r : *wruns) n += (size_t)r.z; n_prims = n > n_prims ? n : n_prims; }
+    if (variant == RT_JIT_WHITTED_HARD && !(wruns && wgeom)) { note = "01 kernel: no strict layout given"; return nullptr; }
     if (n_prims == 0 || n_prims > RT_JIT_MAX_PRIMS) { note = "scene has " + std::to_string(n_prims) + " slots (specialised up to " + std::to_string(RT_JIT_MAX_PRIMS) + ")"; return nullptr; }
     std::string defs;      // RT_MI355_JIT_DEFS=NAME[,NAME...]: extra #defines for the generated source (A/B switches of the device code)
     if (const char* d = getenv("RT_MI355_JIT_DEFS")) {
@@ -307,14 +343,24 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     const char* gen_env = getenv("RT_MI355_JIT_GEN");
     bool has_strict = false;      // slots in the reference's operation sequence (rt_device.h PRIM_*_STRICT): generation 1 only
     for (const int4& r : sruns) has_strict = has_strict || is_strict_type(r.x);
-    const bool gen2 = variant != RT_JIT_WHITTED_SOFT && gen_env && (gen_env[0] == '2' || gen_env[0] == '3') && tmin >= 0.0f && tmax > tmin && std::isfinite(tmax) && !has_strict;
+    const bool gen2 = !whitted && gen_env && (gen_env[0] == '2' || gen_env[0] == '3') && tmin >= 0.0f && tmax > tmin && std::isfinite(tmax) && !has_strict;
     src += (gen2 ? gen_closest_hit_v2(slots, sruns, tmin, tmax, gen_env[0] == '3') : gen_closest_hit(slots, sruns)) + gen_any_hit(slots, sruns);
-    const char* entry = variant == RT_JIT_WHITTED_SOFT ? "k_whitted_jit" : "k_path_jit";
-    if (variant == RT_JIT_WHITTED_SOFT) {   // 02: the generated any-hit query serves the shadow samples - of the monolithic kernel (k_whitted_jit) and of stage 2 of the wavefront form (k_whitted_shadow_jit)
+    const char* entry = whitted ? "k_whitted_jit" : "k_path_jit";
+    std::string strict_gen;
+    if (whitted && wruns && wgeom && !getenv("RT_MI355_JIT_NO_STRICT")) {
+        strict_gen += "#define RT_JIT_STRICT_SCENE 1\n";
+        strict_gen += gen_strict_queries(*wruns, *wgeom);
+    }
+    if (variant == RT_JIT_WHITTED_HARD) {   // 01: whitted_body<false>; registers as needed (no scratch), like the ahead-of-time k_whitted_hard
+        src += std::string(kSrcStrict) + "\n" + strict_gen + kSrcWhitted +
+            "\nextern \"C\" __global__ __launch_bounds__(WBLOCK) void k_whitted_jit(rt::DevScene SD, rt::WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
+            "    rt::whitted_body<false>(SD, A, out, counters);\n}\n";
+    }
+    else if (variant == RT_JIT_WHITTED_SOFT) {   // 02: the generated any-hit query serves the shadow samples - of the monolithic kernel (k_whitted_jit) and of stage 2 of the wavefront form (k_whitted_shadow_jit)
         // waves per SIMD of the monolithic kernel: 7 (72 VGPRs) needs no scratch; 8 (64 VGPRs) spills a few cold values (RT_MI355_WHITTED_WAVES, measured: DESIGN.md 3)
         const char* wv = getenv("RT_MI355_WHITTED_WAVES");
         const std::string waves = (wv && wv[0] >= '4' && wv[0] <= '8' && !wv[1]) ? std::string(wv) : "7";
-        src += std::string(kSrcStrict) + "\n" + kSrcWhitted +
+        src += std::string(kSrcStrict) + "\n" + strict_gen + kSrcWhitted +
             "\nextern \"C\" __global__ __launch_bounds__(WBLOCK) __attribute__((amdgpu_waves_per_eu(" + waves + ", 8))) void k_whitted_jit(rt::DevScene SD, rt::WhittedArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {\n"
             "    rt::whitted_body<true>(SD, A, out, counters);\n}\n"
             "\nextern \"C\" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_whitted_shadow_jit(rt::DevScene SD, rt::WhittedArgs A) {\n"
@@ -334,8 +380,8 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rt_path_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) e.note = "hiprtcCreateProgram failed";
     else {
-        // same code generation as the Makefile's: contraction on (rt_strict.h turns it off for itself), '/' and sqrtf correctly rounded
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt"};
+        // same code generation as the Makefile's: contraction on except where a pragma turns it off (rt_strict.h; '=fast' would let the backend fuse there too), '/' and sqrtf correctly rounded
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast-honor-pragmas", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt"};
         std::vector<const char*> ov(opts, opts + sizeof opts / sizeof opts[0]);
         std::vector<std::string> extra;      // RT_MI355_JIT_FLAGS="-mllvm;-amdgpu-sched-strategy=max-ilp": extra compiler options (experiments; ';'-separated)
         if (const char* xf = getenv("RT_MI355_JIT_FLAGS")) { std::string cur; for (const char* q = xf;; ++q) { if (*q == ';' || *q == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*q) break; } else cur += *q; } }

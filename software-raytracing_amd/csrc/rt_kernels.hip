@@ -195,7 +195,7 @@ void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* 
     // primaryToSecondary < 1): none of the reference's scenes has one, and then no LDS is spent on it (more blocks per CU)
     B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : 0;
     B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed && !(A.debug_flags & 64);
-    if (soft && jit) {   // scene-specialised whitted_body<true>: its shadow samples need no staged slots
+    if (jit) {   // scene-specialised whitted_body<soft>: generated strict queries; 02: its shadow samples need no staged slots
         WhittedArgs J = B; J.shadow_lds = 0;
         DevScene s = S;
         void* params[] = {&s, &J, &out, &counters};

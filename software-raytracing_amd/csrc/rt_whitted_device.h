@@ -68,7 +68,11 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
         if (active) {
             bool done_node = true;   // pop after this node unless a child continues in place
             float t; int idx = -1;
+#ifdef RT_JIT_STRICT_SCENE   // scene-specialised build: the same strict tests, one call per primitive with literal operands (rt_jit.hip)
+            if (depth <= A.max_depth) { ++rays; idx = closest_hit_strict_jit(o, d, tmin, 1000.0f, t); }
+#else
             if (depth <= A.max_depth) { ++rays; idx = strict::closest_hit(S, o, d, tmin, 1000.0f, t); }          // :386-403
+#endif
             if (idx < 0) {
                 acc = madd(sky, weight, acc);                                                            // :489-493
             } else {
@@ -116,7 +120,11 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                                 continue;
                             }
                         } else if (!SOFT) {                                                                     // 01 :435-436
+#ifdef RT_JIT_STRICT_SCENE
+                            if (depth + 1 <= A.max_depth) { ++srays; skip = any_hit_strict_jit(p, tod, 0.01f, len); }
+#else
                             if (depth + 1 <= A.max_depth) { ++srays; skip = strict::any_hit(S, p, tod, 0.01f, len); }
+#endif
                         } else if (depth + 1 <= A.max_depth) {                                           // 02 :452-467, :539-566
                             float per = 1.0f / (float)A.shadow_samples;
                             float tmax_s = len - l0.w;

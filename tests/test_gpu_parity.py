@@ -26,7 +26,7 @@ def test_01_default_resolution(ctx, recorded):
     o = oracle.render_whitted(s, cam, prm, W, H, threads=8)
     assert (g["rays"], g["shadow_rays"]) == (o["rays"], o["shadow_rays"])
     assert g["rays"] + g["shadow_rays"] == recorded["survey"]["01_rays_784x561"]
-    assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.999
+    assert frac_within(g["rgb"], o["rgb"], 2e-6) == 1.0      # every pixel; the last bit of powf apart, the same floats (round 3: -ffp-contract=fast-honor-pragmas)
     db = np.abs(g["bgra"].astype(int) - o["bgra"].astype(int))
     assert db.max() <= 1 and (db.max(axis=-1) > 0).mean() < 1e-3
     # and directly against the reference's own screenshot
@@ -39,18 +39,28 @@ def test_01_default_resolution(ctx, recorded):
 
 def test_01_against_frames_computed_by_the_reference_classes(ctx):
     """HIP vs tests/golden/frame_01.npz (the reference's own classes, oracle/ref_harness_e1.cpp): identical TraceTay counts,
-    >= 99.9 % of pixels within 1e-4 relative of the reference's float colour, bytes within 1 LSB on < 0.1 % of pixels."""
+    EVERY pixel within 2e-6 relative of the reference's float colour and >= 95 % of them bit for bit (what is left is the last bit
+    of powf: ocml vs glibc), bytes within 1 LSB on < 0.1 % of pixels; the generic and the scene-specialised kernel alike.
+    Round 3: the bound was 1e-4 on 99.9 % of the pixels until the build moved from -ffp-contract=fast, which lets the backend
+    fuse multiply-add pairs inside rt_strict.h's pragma-protected arithmetic, to -ffp-contract=fast-honor-pragmas."""
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_01.npz"))
     s, cam, prm = scenes.scene01()
-    g = ctx.render_whitted(s, cam, prm, 196, 140)
-    assert g["rays"] + g["shadow_rays"] == int(gold["rays196"])
-    assert frac_within(g["rgb"], gold["rgb196"], 1e-4) >= 0.999
-    db = np.abs(g["bgra"].astype(int) - gold["bgra196"].astype(int))
-    assert db.max() <= 1 and (db.max(axis=-1) > 0).mean() < 1e-3
-    g = ctx.render_whitted(s, cam, prm, W, H)
-    assert g["rays"] + g["shadow_rays"] == int(gold["rays784"])
-    db = np.abs(g["bgra"].astype(int) - gold["bgra784"].astype(int))
-    assert db.max() <= 1 and (db.max(axis=-1) > 0).mean() < 1e-3
+    for flags, kernel in ((8, 1), (16, 2)):      # generic; specialised at the first render
+        ctx.set_debug_flags(flags)
+        try:
+            g = ctx.render_whitted(s, cam, prm, 196, 140)
+            assert ctx.last_whitted_kernel() == kernel
+            assert g["rays"] + g["shadow_rays"] == int(gold["rays196"])
+            assert frac_within(g["rgb"], gold["rgb196"], 2e-6) == 1.0
+            assert (g["rgb"] == gold["rgb196"]).all(axis=-1).mean() >= 0.95
+            db = np.abs(g["bgra"].astype(int) - gold["bgra196"].astype(int))
+            assert db.max() <= 1 and (db.max(axis=-1) > 0).mean() < 1e-3
+            g = ctx.render_whitted(s, cam, prm, W, H)
+            assert g["rays"] + g["shadow_rays"] == int(gold["rays784"])
+            db = np.abs(g["bgra"].astype(int) - gold["bgra784"].astype(int))
+            assert db.max() <= 1 and (db.max(axis=-1) > 0).mean() < 1e-3
+        finally:
+            ctx.set_debug_flags(0)
 
 
 @pytest.mark.parametrize("samples", [1, 4, 16, 64])
@@ -457,7 +467,8 @@ def test_specialisation_policy_and_cache_across_scenes(ctx):
 
 def test_02_scene_specialised_kernel_matches_generic(ctx):
     """02's shadow samples (16 of its 17 rays per pixel) run generated code for small scenes, like the path kernels'
-    scene query (rt_jit.hip): same arithmetic, so the same image bit for bit and the same ray counts; 01 never specialises."""
+    scene query (rt_jit.hip): same arithmetic, so the same image bit for bit and the same ray counts; the strict queries of the
+    tree walk are generated too (round 3), for 02 and for 01: bit-identical as well."""
     s, cam, prm = scenes.scene02(16, seed=3)
     ctx.set_debug_flags(8 | 4096)      # the generic MONOLITHIC kernel (the generic default is the wavefront form: test_02_wavefront_form_...)
     try:
@@ -473,12 +484,17 @@ def test_02_scene_specialised_kernel_matches_generic(ctx):
     c = ctx.render_whitted(s, cam, prm, 392, 280)            # default policy: this scene has been seen before
     assert ctx.last_whitted_kernel() == 2 and np.array_equal(a["rgb"], c["rgb"])
     s1, cam1, prm1 = scenes.scene01()
-    ctx.set_debug_flags(16)
+    ctx.set_debug_flags(8)
     try:
-        ctx.render_whitted(s1, cam1, prm1, 196, 140)
+        a1 = ctx.render_whitted(s1, cam1, prm1, 392, 280)
         assert ctx.last_whitted_kernel() == 1
+        ctx.set_debug_flags(16)
+        b1 = ctx.render_whitted(s1, cam1, prm1, 392, 280)
+        assert ctx.last_whitted_kernel() == 2, ctx.last_path_kernel()[1]
     finally:
         ctx.set_debug_flags(0)
+    assert (a1["rays"], a1["shadow_rays"]) == (b1["rays"], b1["shadow_rays"])
+    assert np.array_equal(a1["rgb"], b1["rgb"]) and np.array_equal(a1["bgra"], b1["bgra"])      # mirror and glass bounces included: chaotic paths, same bits
 
 
 def test_scene_cache_follows_the_scene_bytes(ctx):
