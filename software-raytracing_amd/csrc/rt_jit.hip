@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <unistd.h>
 
 namespace rt {
 namespace {
@@ -377,8 +378,30 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     if (it != g_cache.end()) { note = it->second.note; if (second) *second = it->second.fn2; return it->second.fn; }
     if (g_cache.size() >= RT_JIT_MAX_SCENES) { note = "more than " + std::to_string(RT_JIT_MAX_SCENES) + " distinct scenes in this process: generic kernel"; return nullptr; }
     Entry e;
+    // RT_MI355_JIT_CACHE=<directory>: compiled code objects are kept there across processes, keyed by the hash of the generated source and the
+    // hiprtc version (a serving process or a render farm pays the ~0.7 s compile once per scene and compiler, not once per process).  Off unless set:
+    // the library writes nowhere it was not pointed at.  A file that fails to load is ignored and rewritten.
+    std::string cache_file;
+    if (const char* dir = getenv("RT_MI355_JIT_CACHE")) {
+        int maj = 0, min = 0; (void)hiprtcVersion(&maj, &min);
+        char name[96]; snprintf(name, sizeof name, "/rt_mi355_%016llx_hiprtc%d.%d_gfx950.co", (unsigned long long)key.second, maj, min);
+        if (dir[0] && !getenv("RT_MI355_JIT_FLAGS")) cache_file = std::string(dir) + name;
+    }
+    bool loaded = false;
+    if (!cache_file.empty()) {
+        if (FILE* f = fopen(cache_file.c_str(), "rb")) {
+            std::vector<char> code; char buf[65536]; size_t n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + n);
+            fclose(f);
+            if (!code.empty() && hipModuleLoadData(&e.mod, code.data()) == hipSuccess && hipModuleGetFunction(&e.fn, e.mod, entry) == hipSuccess) {
+                loaded = true;
+                if (variant == RT_JIT_WHITTED_SOFT && hipModuleGetFunction(&e.fn2, e.mod, "k_whitted_shadow_jit") != hipSuccess) e.fn2 = nullptr;
+            } else { (void)hipGetLastError(); e = Entry(); }
+        }
+    }
     hiprtcProgram prog = nullptr;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "rt_path_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) e.note = "hiprtcCreateProgram failed";
+    if (loaded) { /* nothing to compile */ }
+    else if (hiprtcCreateProgram(&prog, src.c_str(), "rt_path_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) e.note = "hiprtcCreateProgram failed";
     else {
         // same code generation as the Makefile's: contraction on except where a pragma turns it off (rt_strict.h; '=fast' would let the backend fuse there too), '/' and sqrtf correctly rounded
         const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast-honor-pragmas", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt"};
@@ -397,6 +420,14 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
             if (const char* dump = getenv("RT_MI355_JIT_DUMP")) {   // <prefix>.hip = generated source, <prefix>.co = code object (llvm-objdump -d)
                 if (FILE* f = fopen((std::string(dump) + ".hip").c_str(), "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
                 if (FILE* f = fopen((std::string(dump) + ".co").c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+            }
+            if (!cache_file.empty()) {      // written under a temporary name and renamed: a reader never sees half a file
+                const std::string tmp = cache_file + ".tmp" + std::to_string((long long)getpid());
+                if (FILE* f = fopen(tmp.c_str(), "wb")) {
+                    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+                    fclose(f);
+                    if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) (void)remove(tmp.c_str());
+                }
             }
             if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess || hipModuleGetFunction(&e.fn, e.mod, entry) != hipSuccess) { e.fn = nullptr; e.note = "hipModuleLoadData/GetFunction failed"; }
             else if (variant == RT_JIT_WHITTED_SOFT && hipModuleGetFunction(&e.fn2, e.mod, "k_whitted_shadow_jit") != hipSuccess) e.fn2 = nullptr;

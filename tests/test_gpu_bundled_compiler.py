@@ -23,3 +23,21 @@ def test_specialised_kernels_match_generic_under_the_bundled_compiler(ctx):
         assert c["kernels"] == ([1, 2] if name == "02" else [2, 1]), (name, c)               # 03/04: specialised, then generic; 02: generic, then specialised
         assert c["rays"][0] == c["rays"][1] and c["rgb_equal"], (name, c)
         assert c["mean"] > 0.01
+
+
+@pytest.mark.gpu
+def test_jit_cache_on_disk(ctx, tmp_path):
+    """RT_MI355_JIT_CACHE=<dir> (rt_jit.hip): the first process compiles the scene's kernel and leaves its code object there, the second loads it
+    instead of compiling - the same frame bit for bit, both through the specialised kernel, the second start-up well under the compile time."""
+    env = dict(os.environ, RT_MI355_JIT_CACHE=str(tmp_path))
+    env.pop("RT_MI355_JIT", None)
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(HERE, "jit_cache_child.py")], capture_output=True, text=True, timeout=280, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        files = [f for f in os.listdir(tmp_path) if f.endswith(".co")]
+        assert len(files) == 1, files                                  # written once, reused
+    assert runs[0]["kernel"] == runs[1]["kernel"] == 2
+    assert runs[0]["sha"] == runs[1]["sha"] and runs[0]["rays"] == runs[1]["rays"]
+    assert runs[1]["first_render_s"] < 0.5 * runs[0]["first_render_s"], runs
