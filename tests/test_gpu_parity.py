@@ -135,6 +135,19 @@ def test_whitted_recursion_tree_both_branches(ctx):
     o = oracle.render_whitted(s, cam, prm, 96, 64, threads=8)
     assert (g["rays"], g["shadow_rays"]) == (o["rays"], o["shadow_rays"])
     assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.99
+    # the scene-specialised kernels on this scene (generated strict queries incl. the triangle test, LDS stack of the branching tree): the generic kernels' bits
+    for samples in (0, 3):
+        prm = scenes.whitted_params(4, samples, seed=9)
+        ctx.set_debug_flags(8 | 4096)
+        try:
+            a = ctx.render_whitted(s, cam, prm, 200, 150)
+            assert ctx.last_whitted_kernel() == 1
+            ctx.set_debug_flags(16)
+            b = ctx.render_whitted(s, cam, prm, 200, 150)
+            assert ctx.last_whitted_kernel() == 2, ctx.last_path_kernel()[1]
+        finally:
+            ctx.set_debug_flags(0)
+        assert (a["rays"], a["shadow_rays"]) == (b["rays"], b["shadow_rays"]) and np.array_equal(a["rgb"], b["rgb"]), samples
 
 
 # ---- 03 / 04 ---------------------------------------------------------------------------------------
