@@ -71,8 +71,13 @@ def test_02_shadow_sample_sweep(ctx, samples):
     o = oracle.render_whitted(s, cam, prm, w, h, threads=8)
     assert g["rays"] == o["rays"] == w * h
     assert g["shadow_rays"] == o["shadow_rays"] == samples * w * h      # exactly 1 + samples rays per pixel
-    assert frac_within(g["rgb"], o["rgb"], 1e-4) >= 0.998
-    assert abs(g["rgb"].mean() - o["rgb"].mean()) < 1e-4
+    # the tree walk is the reference's arithmetic bit for bit, so a pixel differs only when one of its shadow samples (fast tests, on purpose:
+    # rt_strict.h fastshadow) decides a grazing occluder the other way - 1/samples of one light's contribution.  Measured: 0 or 1 such pixel per frame
+    # (tools/whitted02_vs_oracle.py); round 2's bound was 99.8 % within 1e-4.
+    rel = (np.abs(g["rgb"] - o["rgb"]) / np.maximum(np.abs(o["rgb"]), 1e-3)).max(axis=2)
+    assert (rel > 2e-6).sum() <= max(3, int(2e-5 * w * h)), int((rel > 2e-6).sum())
+    assert (rel == 0).mean() >= 0.98
+    assert abs(g["rgb"].mean() - o["rgb"].mean()) < 1e-5
 
 
 def test_02_first_primitive_casts_shadows(ctx):
