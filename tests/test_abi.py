@@ -171,3 +171,15 @@ def test_prefer_system_compiler_is_safe_to_call_any_time():
         assert L.SYSTEM_COMGR in conftest.JIT_COMPILER
     import torch  # noqa: F401
     assert "PyTorch" in L.prefer_system_compiler()
+
+
+def test_device_code_is_built_with_pragma_honouring_contraction():
+    """-ffp-contract=fast lets the backend fuse multiply-adds inside rt_strict.h's '#pragma clang fp contract(off)' arithmetic (found in round 3: 01 then
+    differs from the reference-made frame by up to 2.4e-4 instead of 2e-7).  Both builds - the Makefile's and the hiprtc options - must say fast-honor-pragmas."""
+    import re
+    mk = open(os.path.join(ROOT, "software-raytracing_amd", "Makefile")).read()
+    jit = open(os.path.join(ROOT, "software-raytracing_amd", "csrc", "rt_jit.hip")).read()
+    flags = [l for l in mk.splitlines() if l.startswith("FLAGS")][0]
+    assert "-ffp-contract=fast-honor-pragmas" in flags and not re.search(r"-ffp-contract=fast(\s|$)", flags)
+    opts = [l for l in jit.splitlines() if "const char* opts[]" in l][0]
+    assert '"-ffp-contract=fast-honor-pragmas"' in opts and '"-ffp-contract=fast"' not in opts and "-fhip-fp32-correctly-rounded-divide-sqrt" in opts
