@@ -20,6 +20,8 @@ struct strict {
 static __device__ __forceinline__ f3 add(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static __device__ __forceinline__ f3 sub(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static __device__ __forceinline__ f3 muls(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+static __device__ __forceinline__ f3 mulv(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static __device__ __forceinline__ f3 mix(f3 a, f3 b, float r) { return add(a, muls(sub(b, a), r)); }                 // math::Mix (Math.hpp:323-326): a + ((b - a) * ratio)
 static __device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }          // Math.hpp:261-264
 static __device__ __forceinline__ f3 cross(f3 a, f3 b) {                                                               // Math.hpp:274-281
     return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);

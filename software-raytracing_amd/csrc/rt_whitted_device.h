@@ -8,6 +8,19 @@
 namespace rt {
 
 #define WBLOCK 128
+// The specular term's powf (01 Main.cpp:441, 02 Main.cpp:472).  The reference's value comes from its platform's libm; glibc's powf - what the oracle and the
+// reference-made goldens use - is correctly rounded in all but ~1e-4 of its results, the device library's is good to 1-2 ulp: that was the last bit in which 2.2 % of
+// 01's pixels differed from the reference-made frame.  Shininess is a whole number in every scene of the reference (16, 128, 512): x^n by squaring in DOUBLE (<= 2 log2 n
+// roundings of 1.1e-16) rounded to float once is the correctly rounded float but for ~1e-7 of the arguments, i.e. glibc's value.  Other exponents keep the device powf
+// (an inlined double pow() costs the kernels 50-60 VGPRs: measured, 02 then spills 192 B per lane).
+__device__ __forceinline__ float pow_specular(float x, float y) {
+    if (y >= 0.0f && y <= 65536.0f && y == truncf(y)) {
+        double b = (double)x, r = 1.0;
+        for (uint32_t n = (uint32_t)y; n != 0U; n >>= 1) { if (n & 1U) r *= b; b *= b; }
+        return (float)r;
+    }
+    return powf(x, y);
+}
 // WALK = false: the whole of TraceTay in one kernel (shadow rays traced where the hit is shaded).
 // WALK = true: stage 1 of the WAVEFRONT form - the tree walk only.  Where TraceTay traces the shadow rays of a shaded hit
 // (01 Main.cpp:435-436, 02 Main.cpp:452-467) this stage writes a request {hit point, pixel, unshadowed contribution of the light,
@@ -63,6 +76,13 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
     unsigned int rays = 0, srays = 0;
     bool active = inside;
     const f3 sky = F3(0.2f, 0.7f, 0.8f);
+    // CHAIN mode (round 3): when no material spawns reflection AND refraction at one hit (none of the reference's does) a pixel's recursion tree is a chain, and the
+    // colour is evaluated as the reference evaluates it - bottom-up, Mix(primary, Mix(refl, refr, wr), wp) per level in its own operation order (01 Main.cpp:480-484) -
+    // instead of as a weighted sum of the levels' contributions, which is the same number only in exact arithmetic (it was the last bit in which 2.2 % of 01's pixels
+    // still differed from the reference-made frame).  Each level leaves {primary, wp, wr | flags} in LDS (5 floats; the branching stack is not needed then, so the
+    // space is its); when the chain ends the lane folds the levels back from the deepest.  Branching trees and the wavefront walk keep the weighted sum.
+    const bool chain = !WALK && !SD.whitted_branches;
+    float (*lvl)[5][WBLOCK] = reinterpret_cast<float (*)[5][WBLOCK]>(stk_raw);
 
     while (__any(active)) {
         if (active) {
@@ -73,8 +93,9 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
 #else
             if (depth <= A.max_depth) { ++rays; idx = strict::closest_hit(S, o, d, tmin, 1000.0f, t); }          // :386-403
 #endif
+            f3 leaf = F3(0, 0, 0);   // CHAIN mode: the colour of the node the chain ends in (a hit without a child leaves its own record and a black child)
             if (idx < 0) {
-                acc = madd(sky, weight, acc);                                                            // :489-493
+                if (chain) leaf = sky; else acc = madd(sky, weight, acc);                                // :489-493
             } else {
                 int4 inf = S.info[idx];
                 f3 p = strict::add(o, strict::muls(d, t));                                               // :414
@@ -82,6 +103,7 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                 float4 m0 = S.mats[inf.z * 3], m1 = S.mats[inf.z * 3 + 1], m2 = S.mats[inf.z * 3 + 2];
                 float p2s = m1.z, r2r = m1.w;
                 float wp = fmaxf(1.0f - p2s, 0.0f), wr = fmaxf(1.0f - r2r, 0.0f);
+                f3 primary = F3(0, 0, 0);
                 if (p2s > 0.0f) {                                                                        // :421-447
                     f3 diffuse = F3(0, 0, 0), specular = F3(0, 0, 0);
                     for (int li = 0; li < S.n_lights; ++li) {
@@ -96,7 +118,7 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                             if (depth + 1 <= A.max_depth) {      // shadow rays apply: hand the light's contribution to the shadow stage
                                 float dd = fmaxf(0.0f, strict::dot(tod, n));
                                 float sdot = fmaxf(0.0f, strict::dot(strict::reflect(-tod, n), -d));
-                                float sp = powf(sdot, m1.y);
+                                float sp = pow_specular(sdot, m1.y);
                                 const f3 cl = (F3(l1) * dd * F3(m0) + F3(l1) * sp * m1.x) * (weight * (1.0f - wp));
                                 // slot: a primary hit's request sits at pixel * lights + light (no atomic: 8 million of them on one
                                 // counter would cost more than the frame); deeper nodes draw from the region behind, one atomic per wave
@@ -151,12 +173,17 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                         if (skip) continue;   // 01: an occluded light is skipped entirely
                         float dd = fmaxf(0.0f, strict::dot(tod, n));
                         float sdot = fmaxf(0.0f, strict::dot(strict::reflect(-tod, n), -d));
-                        float sp = powf(sdot, m1.y);
-                        diffuse = madd(F3(l1), dd * intensity, diffuse);
-                        specular = madd(F3(l1), sp * intensity, specular);
+                        float sp = pow_specular(sdot, m1.y);
+                        if (SOFT) {                                                                      // 02 :474-477: (colour * term) * intensity
+                            diffuse = strict::add(diffuse, strict::muls(strict::muls(F3(l1), dd), intensity));
+                            specular = strict::add(specular, strict::muls(strict::muls(F3(l1), sp), intensity));
+                        } else {                                                                         // 01 :439-442
+                            diffuse = strict::add(diffuse, strict::muls(F3(l1), dd));
+                            specular = strict::add(specular, strict::muls(F3(l1), sp));
+                        }
                     }
-                    f3 primary = diffuse * F3(m0) + specular * m1.x;                                     // :446
-                    acc = madd(primary, weight * (1.0f - wp), acc);
+                    primary = strict::add(strict::mulv(diffuse, F3(m0)), strict::muls(specular, m1.x));  // :446
+                    if (!chain) acc = madd(primary, weight * (1.0f - wp), acc);
                 }
                 if (p2s < 1.0f) {                                                                        // :450-481
                     bool do_refl = r2r > 0.0f, do_refr = r2r < 1.0f;
@@ -182,8 +209,31 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                         done_node = false;
                     }
                 }
+                if (chain) {             // this level's record ('depth' has already moved on when a child continues); wp, wr and which child there is follow from p2s, r2r
+                    const int lv = done_node ? depth : depth - 1;
+                    lvl[lv][0][tid] = primary.x; lvl[lv][1][tid] = primary.y; lvl[lv][2][tid] = primary.z;
+                    lvl[lv][3][tid] = p2s; lvl[lv][4][tid] = r2r;
+                }
             }
-            if (done_node) {
+            if (done_node && chain) {
+                // the chain has ended: in a miss / beyond the depth limit (the sky; levels 0 .. depth-1 above it) or in a hit without a child (its own level on top).
+                // TraceTay's return path, level by level (01 Main.cpp:450-484): secondary = Mix(refl, refr, wr) with the child in its place and black in the other,
+                // colour = Mix(primary, secondary, wp); a level without a secondary term mixes with black at wp = 0, as the reference does.
+                f3 c = leaf;
+                for (int lv = (idx < 0) ? depth - 1 : depth; lv >= 0; --lv) {
+                    const f3 prim = F3(lvl[lv][0][tid], lvl[lv][1][tid], lvl[lv][2][tid]);
+                    const float lp2s = lvl[lv][3][tid], lr2r = lvl[lv][4][tid];
+                    f3 secondary = F3(0, 0, 0);
+                    if (lp2s < 1.0f) {
+                        const bool child_is_refl = lr2r > 0.0f;      // chain: exactly one of the two children exists
+                        const f3 refl = child_is_refl ? c : F3(0, 0, 0), refr = child_is_refl ? F3(0, 0, 0) : c;
+                        secondary = strict::mix(refl, refr, fmaxf(1.0f - lr2r, 0.0f));
+                    }
+                    c = strict::mix(prim, secondary, fmaxf(1.0f - lp2s, 0.0f));
+                }
+                acc = c;
+                active = false;
+            } else if (done_node) {
                 if (pending == 0U) active = false;
                 else {
                     int k = 31 - __clz((int)pending);
