@@ -193,8 +193,8 @@ void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* 
     WhittedArgs B = A;
     // the stack only ever holds the refraction child of a hit that ALSO reflects (0 < reflectToRefract < 1 on a material with
     // primaryToSecondary < 1): none of the reference's scenes has one, and then no LDS is spent on it (more blocks per CU)
-    // branching trees: the stack of parked siblings; chains (every scene of the reference): the per-level records of the bottom-up colour evaluation (5 floats per level)
-    B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : (A.max_depth + 1) * 5 * WBLOCK * (int)sizeof(float);
+    // branching trees: the stack of parked siblings; chains (every scene of the reference): the per-level records of the bottom-up colour evaluation (4 floats per level)
+    B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : (A.max_depth + 1) * 4 * WBLOCK * (int)sizeof(float);
     B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed && !(A.debug_flags & 64);
     if (jit) {   // scene-specialised whitted_body<soft>: generated strict queries; 02: its shadow samples need no staged slots
         WhittedArgs J = B; J.shadow_lds = 0;

@@ -79,10 +79,10 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
     // CHAIN mode (round 3): when no material spawns reflection AND refraction at one hit (none of the reference's does) a pixel's recursion tree is a chain, and the
     // colour is evaluated as the reference evaluates it - bottom-up, Mix(primary, Mix(refl, refr, wr), wp) per level in its own operation order (01 Main.cpp:480-484) -
     // instead of as a weighted sum of the levels' contributions, which is the same number only in exact arithmetic (it was the last bit in which 2.2 % of 01's pixels
-    // still differed from the reference-made frame).  Each level leaves {primary, wp, wr | flags} in LDS (5 floats; the branching stack is not needed then, so the
-    // space is its); when the chain ends the lane folds the levels back from the deepest.  Branching trees and the wavefront walk keep the weighted sum.
+    // still differed from the reference-made frame).  Each level leaves {primary, material} in LDS (4 floats - 10 KB per block at depth 4, so 14 blocks = 7 waves per SIMD still fit a CU; the branching
+    // stack is not needed then, so the space is its); when the chain ends the lane folds the levels back from the deepest.  Branching trees and the wavefront walk keep the weighted sum.
     const bool chain = !WALK && !SD.whitted_branches;
-    float (*lvl)[5][WBLOCK] = reinterpret_cast<float (*)[5][WBLOCK]>(stk_raw);
+    float (*lvl)[4][WBLOCK] = reinterpret_cast<float (*)[4][WBLOCK]>(stk_raw);
 
     while (__any(active)) {
         if (active) {
@@ -209,10 +209,10 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                         done_node = false;
                     }
                 }
-                if (chain) {             // this level's record ('depth' has already moved on when a child continues); wp, wr and which child there is follow from p2s, r2r
+                if (chain) {             // this level's record ('depth' has already moved on when a child continues); wp, wr and which child there is follow from the material's p2s, r2r
                     const int lv = done_node ? depth : depth - 1;
                     lvl[lv][0][tid] = primary.x; lvl[lv][1][tid] = primary.y; lvl[lv][2][tid] = primary.z;
-                    lvl[lv][3][tid] = p2s; lvl[lv][4][tid] = r2r;
+                    lvl[lv][3][tid] = __int_as_float(inf.z);
                 }
             }
             if (done_node && chain) {
@@ -222,7 +222,8 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                 f3 c = leaf;
                 for (int lv = (idx < 0) ? depth - 1 : depth; lv >= 0; --lv) {
                     const f3 prim = F3(lvl[lv][0][tid], lvl[lv][1][tid], lvl[lv][2][tid]);
-                    const float lp2s = lvl[lv][3][tid], lr2r = lvl[lv][4][tid];
+                    const float4 lm1 = S.mats[__float_as_int(lvl[lv][3][tid]) * 3 + 1];
+                    const float lp2s = lm1.z, lr2r = lm1.w;
                     f3 secondary = F3(0, 0, 0);
                     if (lp2s < 1.0f) {
                         const bool child_is_refl = lr2r > 0.0f;      // chain: exactly one of the two children exists
