@@ -1,8 +1,8 @@
 // Build and run (CPU only; the instrumented library goes to /tmp, not into the tree):
-//   cd software-raytracing_amd && hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -fno-slp-vectorize \
+//   cd software-raytracing_amd && hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast-honor-pragmas -fno-slp-vectorize \
 //       -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -shared -o /tmp/asan/librt_mi355.so csrc/rt_api.hip csrc/rt_kernels.hip csrc/rt_jit.hip -lhiprtc
 //   clang++ -O1 -g -std=c++17 -fsanitize=address,undefined -Iinclude tools/host_asan_check.cpp -o /tmp/asan/check -L/tmp/asan -lrt_mi355 -Wl,-rpath,/tmp/asan -Wl,-rpath,/opt/rocm/lib
-//   ASAN_OPTIONS=detect_leaks=0 /tmp/asan/check      (round 2: 300 scenes up to 20,000 primitives, no report)
+//   ASAN_OPTIONS=detect_leaks=0 /tmp/asan/check      (round 2: 300 scenes up to 20,000 primitives, no report; round 3: + 200 scenes built around coplanar elements, no report)
 // Host-side sanitizer check of the scene compiler and the BVH builder: random scenes of every primitive type through
 // rt_debug_bvh_probe (CPU only: no GPU call is made).  Built with -fsanitize=address,undefined together with an
 // ASan-instrumented host build of librt_mi355.so.
@@ -52,6 +52,34 @@ int main() {
     p.type = RT_PRIM_SPHERE; p.material = 5;
     std::printf("material out of range: %d\n", rt_debug_bvh_probe(&badtype, 4, out));
     for (int n = 1; n <= 9; ++n) for (int i = 0; i < n; ++i) { int32_t b, e; rt_debug_group_share(0, 1000003, i, n, &b, &e); }
+    // round 3: scenes built AROUND coplanar planar elements (floor planes, boxes resting on them at random turns about the vertical, rectangles and triangles lying in
+    // the floor or in each other's planes, duplicates): the detection of compile_scene (find_coplanar: outlines, separating axes, pair budget) under the sanitizers
+    for (int it = 0; it < 200; ++it) {
+        std::vector<rt_material> mats(2); memset(mats.data(), 0, mats.size() * sizeof(rt_material));
+        mats[0].type = RT_MAT_DIFFUSE; mats[1].type = RT_MAT_DIELECTRIC; mats[1].refraction_index = 0.66f;
+        const int n = 2 + (int)(g() % (it < 190 ? 40 : 3000));
+        std::vector<rt_prim> prims((size_t)n); memset(prims.data(), 0, prims.size() * sizeof(rt_prim));
+        const float floor_y = -2.0f;
+        prims[0].type = RT_PRIM_PLANE; prims[0].f[1] = floor_y; prims[0].f[4] = 1.0f;
+        for (int k = 1; k < n; ++k) {
+            rt_prim& P = prims[(size_t)k]; float* f = P.f;
+            P.material = (int32_t)(g() % 2);
+            const float cx = 8.0f * U(g), cz = -6.0f + 5.0f * U(g), sx = 0.2f + 1.5f * std::fabs(U(g)), sy = 0.2f + 1.5f * std::fabs(U(g)), sz = 0.2f + 1.5f * std::fabs(U(g));
+            switch (g() % 4) {
+            case 0: P.type = RT_PRIM_BOX; f[0] = cx; f[1] = floor_y + sy / 2.0f; f[2] = cz; f[3] = sx; f[4] = sy; f[5] = sz; f[7] = (g() % 3) ? 90.0f * U(g) : 0.0f; break;
+            case 1: P.type = RT_PRIM_RECT; f[0] = cx; f[1] = floor_y; f[2] = cz; f[3] = sx; f[4] = sz; f[5] = 90.0f; f[6] = (g() % 2) ? 45.0f * U(g) : 0.0f; break;
+            case 2: P.type = RT_PRIM_TRIANGLE; f[0] = cx; f[1] = floor_y; f[2] = cz; f[3] = cx + sx; f[4] = floor_y; f[5] = cz; f[6] = cx; f[7] = floor_y; f[8] = cz - sz; break;
+            default: prims[(size_t)k] = prims[(size_t)(1 + g() % (unsigned)k) % (size_t)k == 0 ? 0 : (size_t)(g() % (unsigned)k)]; break;      // a duplicate of an earlier element
+            }
+        }
+        rt_scene sc{}; sc.prims = prims.data(); sc.n_prims = n; sc.materials = mats.data(); sc.n_materials = 2;
+        for (int variant = 3; variant <= 4; ++variant) {
+            int32_t out[5] = {0, 0, 0, 0, 0};
+            const int rc = rt_debug_bvh_probe(&sc, variant, out);
+            ++scenes;
+            if (rc != 0) { ++bad; std::printf("coplanar scene %d variant %d: probe returned %d (%s)\n", it, variant, rc, rt_last_error(nullptr)); }
+        }
+    }
     std::printf("%ld scenes, %ld probe failures\n", scenes, bad);
     return bad ? 1 : 0;
 }
