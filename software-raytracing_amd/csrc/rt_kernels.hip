@@ -193,9 +193,10 @@ void launch_whitted(bool soft, const DevScene& S, const WhittedArgs& A, float4* 
     WhittedArgs B = A;
     // the stack only ever holds the refraction child of a hit that ALSO reflects (0 < reflectToRefract < 1 on a material with
     // primaryToSecondary < 1): none of the reference's scenes has one, and then no LDS is spent on it (more blocks per CU)
-    // branching trees: the stack of parked siblings; chains (every scene of the reference): the per-level records of the bottom-up colour evaluation (4 floats per level)
-    B.stack_bytes = S.whitted_branches ? (A.max_depth + 2) * 8 * WBLOCK * (int)sizeof(float) : (A.max_depth + 1) * 4 * WBLOCK * (int)sizeof(float);
-    B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed && !(A.debug_flags & 64);
+    // per level: the record of the bottom-up colour evaluation (4 floats); branching trees: + the parked refraction child / the reflection's colour (8 floats)
+    B.stack_bytes = (A.max_depth + 1) * (S.whitted_branches ? 12 : 4) * WBLOCK * (int)sizeof(float);
+    B.shadow_lds = soft && S.slot_bytes > 0 && S.slot_bytes <= RT_TILE_BYTES && S.srun_packed && !(A.debug_flags & 64) &&
+                   (size_t)B.stack_bytes + (size_t)S.slot_bytes + 256 <= 65536;      // depth 8 of a branching tree is 54 KB of records
     if (jit) {   // scene-specialised whitted_body<soft>: generated strict queries; 02: its shadow samples need no staged slots
         WhittedArgs J = B; J.shadow_lds = 0;
         DevScene s = S;

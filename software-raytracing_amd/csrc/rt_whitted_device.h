@@ -76,13 +76,19 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
     unsigned int rays = 0, srays = 0;
     bool active = inside;
     const f3 sky = F3(0.2f, 0.7f, 0.8f);
-    // CHAIN mode (round 3): when no material spawns reflection AND refraction at one hit (none of the reference's does) a pixel's recursion tree is a chain, and the
-    // colour is evaluated as the reference evaluates it - bottom-up, Mix(primary, Mix(refl, refr, wr), wp) per level in its own operation order (01 Main.cpp:480-484) -
-    // instead of as a weighted sum of the levels' contributions, which is the same number only in exact arithmetic (it was the last bit in which 2.2 % of 01's pixels
-    // still differed from the reference-made frame).  Each level leaves {primary, material} in LDS (4 floats - 10 KB per block at depth 4, so 14 blocks = 7 waves per SIMD still fit a CU; the branching
-    // stack is not needed then, so the space is its); when the chain ends the lane folds the levels back from the deepest.  Branching trees and the wavefront walk keep the weighted sum.
-    const bool chain = !WALK && !SD.whitted_branches;
+    // Monolithic kernels (round 3): the colour is evaluated as the reference evaluates it - bottom-up, Mix(primary, Mix(refl, refr, wr), wp) per level in its own operation
+    // order (01 Main.cpp:480-484) - instead of as a weighted sum of the nodes' contributions, which is the same number only in exact arithmetic (it was the last bit in
+    // which 2.2 % of 01's pixels still differed from the reference-made frame).  Each level of the current root-to-node path leaves {primary, material} in LDS (4 floats);
+    // when a node has returned, the lane folds the levels back from the deepest.  A chain (no material spawns reflection AND refraction at one hit - none of the
+    // reference's does) needs nothing else: 10 KB per block at depth 4, 14 blocks = 7 waves per SIMD per CU.  A branching tree parks the refraction child of a node while
+    // its reflection subtree is walked (8 floats per level behind the records); when the fold reaches such a level it leaves the reflection's colour in the parked
+    // child's place, walks the refraction subtree, and folds on from there with both colours in hand: post-order, as the recursion returns.  The wavefront walk keeps
+    // the weighted sum (its shadow terms are only known after stage 2).
+    constexpr bool chain = !WALK;
     float (*lvl)[4][WBLOCK] = reinterpret_cast<float (*)[4][WBLOCK]>(stk_raw);
+    // parked children: WALK - slot cd of the stack; else slot cd - 1 behind the max_depth + 1 level records
+    float (*park)[8][WBLOCK] = WALK ? stk : reinterpret_cast<float (*)[8][WBLOCK]>(stk_raw + (A.max_depth + 1) * 4 * WBLOCK) - 1;
+    uint32_t has_refl = 0U;             // bit lv: level lv's reflection colour is known (kept in the first three floats of park[lv + 1])
 
     while (__any(active)) {
         if (active) {
@@ -197,9 +203,9 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                     }
                     int cd = depth + 1;
                     if (do_refl && do_refr) {   // park the refraction child in the slot of its depth
-                        stk[cd][0][tid] = p.x; stk[cd][1][tid] = p.y; stk[cd][2][tid] = p.z;
-                        stk[cd][3][tid] = d_refr.x; stk[cd][4][tid] = d_refr.y; stk[cd][5][tid] = d_refr.z;
-                        stk[cd][6][tid] = w_refr; stk[cd][7][tid] = __uint_as_float(node * 2U + 1U);
+                        park[cd][0][tid] = p.x; park[cd][1][tid] = p.y; park[cd][2][tid] = p.z;
+                        park[cd][3][tid] = d_refr.x; park[cd][4][tid] = d_refr.y; park[cd][5][tid] = d_refr.z;
+                        park[cd][6][tid] = w_refr; park[cd][7][tid] = __uint_as_float(node * 2U + 1U);
                         pending |= 1U << cd;
                     }
                     if (do_refl || do_refr) {
@@ -216,32 +222,45 @@ __device__ __forceinline__ void whitted_body(const DevScene& SD, const WhittedAr
                 }
             }
             if (done_node && chain) {
-                // the chain has ended: in a miss / beyond the depth limit (the sky; levels 0 .. depth-1 above it) or in a hit without a child (its own level on top).
-                // TraceTay's return path, level by level (01 Main.cpp:450-484): secondary = Mix(refl, refr, wr) with the child in its place and black in the other,
-                // colour = Mix(primary, secondary, wp); a level without a secondary term mixes with black at wp = 0, as the reference does.
+                // a node has returned: a miss / beyond the depth limit (the sky; levels 0 .. depth-1 above it) or a hit without a child (its own level on top).
+                // TraceTay's return path, level by level (01 Main.cpp:450-484): secondary = Mix(refl, refr, wr) with the children's colours (black for a child
+                // that was not traced), colour = Mix(primary, secondary, wp); a level without a secondary term mixes with black at wp = 0, as the reference does.
                 f3 c = leaf;
+                bool resumed = false;
                 for (int lv = (idx < 0) ? depth - 1 : depth; lv >= 0; --lv) {
+                    if (pending & (2U << lv)) {      // c is the reflection's colour and the refraction child is still parked: keep c in its place and walk that subtree
+                        pending &= ~(2U << lv); has_refl |= 1U << lv;
+                        o = F3(park[lv + 1][0][tid], park[lv + 1][1][tid], park[lv + 1][2][tid]);
+                        d = F3(park[lv + 1][3][tid], park[lv + 1][4][tid], park[lv + 1][5][tid]);
+                        node = __float_as_uint(park[lv + 1][7][tid]);
+                        park[lv + 1][0][tid] = c.x; park[lv + 1][1][tid] = c.y; park[lv + 1][2][tid] = c.z;
+                        depth = lv + 1; tmin = 0.001f;
+                        resumed = true;
+                        break;
+                    }
                     const f3 prim = F3(lvl[lv][0][tid], lvl[lv][1][tid], lvl[lv][2][tid]);
                     const float4 lm1 = S.mats[__float_as_int(lvl[lv][3][tid]) * 3 + 1];
                     const float lp2s = lm1.z, lr2r = lm1.w;
                     f3 secondary = F3(0, 0, 0);
                     if (lp2s < 1.0f) {
-                        const bool child_is_refl = lr2r > 0.0f;      // chain: exactly one of the two children exists
-                        const f3 refl = child_is_refl ? c : F3(0, 0, 0), refr = child_is_refl ? F3(0, 0, 0) : c;
+                        f3 refl = c, refr = F3(0, 0, 0);                   // the only child is the reflection
+                        if (has_refl & (1U << lv)) {                       // both children: c is the refraction's colour
+                            refl = F3(park[lv + 1][0][tid], park[lv + 1][1][tid], park[lv + 1][2][tid]); refr = c;
+                            has_refl &= ~(1U << lv);
+                        } else if (!(lr2r > 0.0f)) { refl = F3(0, 0, 0); refr = c; }      // the only child is the refraction
                         secondary = strict::mix(refl, refr, fmaxf(1.0f - lr2r, 0.0f));
                     }
                     c = strict::mix(prim, secondary, fmaxf(1.0f - lp2s, 0.0f));
                 }
-                acc = c;
-                active = false;
+                if (!resumed) { acc = c; active = false; }
             } else if (done_node) {
                 if (pending == 0U) active = false;
                 else {
                     int k = 31 - __clz((int)pending);
                     pending &= ~(1U << k);
-                    o = F3(stk[k][0][tid], stk[k][1][tid], stk[k][2][tid]);
-                    d = F3(stk[k][3][tid], stk[k][4][tid], stk[k][5][tid]);
-                    weight = stk[k][6][tid]; node = __float_as_uint(stk[k][7][tid]);
+                    o = F3(park[k][0][tid], park[k][1][tid], park[k][2][tid]);
+                    d = F3(park[k][3][tid], park[k][4][tid], park[k][5][tid]);
+                    weight = park[k][6][tid]; node = __float_as_uint(park[k][7][tid]);
                     depth = k; tmin = 0.001f;
                 }
             }
