@@ -199,6 +199,21 @@ int32_t rt_abi_version(void);
 #define RT_OPT_ACCEL  1
 #define RT_ACCEL_NONE 0
 #define RT_ACCEL_BVH  1
+/* RT_OPT_ARITHMETIC: how closely the path renders follow the reference's floating-point operation sequence.
+ *   RT_ARITH_FAST (default):  fused multiply-adds, hardware reciprocals and roots, directions that are unit by construction.  The
+ *                             same paths as the reference's arithmetic in all but the cases the last bits decide; planar elements
+ *                             that coincide and spheres of radius > 30000 tMin (03's ground sphere) are tested in the
+ *                             reference's own operation sequence, because there those bits decide OFTEN.
+ *   RT_ARITH_REFERENCE:       every ray direction normalised as Ray's constructor does (Common/Ray.hpp:33-34), every sphere
+ *                             tested with Ray::intersectsSphere's own operations (Common/Ray.hpp:105-121: a = d.d, true
+ *                             divisions, correctly rounded root), hit points rounded as the reference rounds them.  For scenes
+ *                             of small spheres far from where the rays start (|o - c| >> r) at a small tMin, where a ray
+ *                             re-hits the surface it leaves at a rate the rounding sets: scene queries per sample then follow
+ *                             the reference to ~3e-4 instead of ~1e-2.  Costs about 40 % on 03; brute force and one lane per
+ *                             pixel only (RT_ACCEL_BVH is refused).  Whitted renders are reference arithmetic always. */
+#define RT_OPT_ARITHMETIC  2
+#define RT_ARITH_FAST      0
+#define RT_ARITH_REFERENCE 1
 int32_t rt_set_option(rt_ctx* ctx, int32_t option, int32_t value);
 
 /* Fills params with the committed constants of the named example (1..4). */

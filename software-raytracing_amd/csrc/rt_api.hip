@@ -164,6 +164,7 @@ struct rt_ctx {
     } prog;
     DevBuf prog_sum;
     int accel = 0;                                // RT_OPT_ACCEL: 0 brute force (the reference's algorithm), 1 BVH
+    int arith = 0;                                // RT_OPT_ARITHMETIC: 0 fast, 1 the reference's operation sequence for rays and spheres
     // what scene_buf holds: a render of the same scene (same bytes, variant, BVH or not, stream) skips compile, build and upload
     bool cache_valid = false; uint64_t cache_key = 0; hipStream_t cache_stream = nullptr;
     std::vector<unsigned char> cache_bytes;       // the rt_scene records the cache was built from: a hit is confirmed by comparing them, not by the hash alone
@@ -387,7 +388,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
             float strict_pts[12]; int n_strict_pts = 0;      // a strict rectangle's corners (its slot no longer holds plane rows to bound it by)
             switch (P.type) {
             case RT_PRIM_SPHERE: {
-                if (variant != 0 && fabsf(f[3]) > RT_BIG_SPHERE_RATIO * tmin) dtype = PRIM_SPHERE_BIG;
+                if (variant != 0 && (fabsf(f[3]) > RT_BIG_SPHERE_RATIO * tmin || (c && c->arith == RT_ARITH_REFERENCE))) dtype = PRIM_SPHERE_BIG;      // reference arithmetic: every sphere
                 G = f4(f[0], f[1], f[2], f[3] * f[3]);
                 A = f4(f[0], f[1], f[2], (P.flags & RT_PRIM_FLAG_FLIP_NORMALS) ? -1.0f : 1.0f);
                 break; }
@@ -611,7 +612,7 @@ int prepare_scene(rt_ctx* c, const rt_scene* scene, int variant, float tmin, boo
         (scene->n_materials && !scene->materials) || (scene->n_lights && !scene->lights)) {
         HostScene tmp; return compile_scene(c, scene, variant, tmin, tmp);      // reports the error
     }
-    const uint64_t key = scene_key(scene, variant, accel ? 1 : 0, tmin);
+    const uint64_t key = scene_key(scene, variant | (c->arith << 8), accel ? 1 : 0, tmin);
     const size_t nb_p = (size_t)scene->n_prims * sizeof(rt_prim), nb_m = (size_t)scene->n_materials * sizeof(rt_material), nb_l = (size_t)scene->n_lights * sizeof(rt_light);
     bool hit = c->cache_valid && c->cache_key == key && c->cache_stream == st && c->cache_bytes.size() == nb_p + nb_m + nb_l;
     if (hit) {   // a 64-bit hash can collide: the cached blob is only reused for the very same records
@@ -877,6 +878,12 @@ int32_t rt_set_option(rt_ctx* c, int32_t option, int32_t value) {
         c->accel = value;
         return RT_OK;
     }
+    if (option == RT_OPT_ARITHMETIC) {
+        if (value != RT_ARITH_FAST && value != RT_ARITH_REFERENCE) return fail(c, RT_ERR_BAD_ARG, "RT_OPT_ARITHMETIC: value must be RT_ARITH_FAST or RT_ARITH_REFERENCE");
+        c->arith = value;
+        for (rt_ctx* d : c->peers) if (d) d->arith = value;
+        return RT_OK;
+    }
     return fail(c, RT_ERR_BAD_ARG, "rt_set_option: unknown option " + std::to_string(option));
 }
 
@@ -908,7 +915,8 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     if (s0 == 0 && s1 == 0) s1 = p->spp;
     if (p->spp <= 0 || s0 < 0 || s1 < s0 || p->max_depth < 0) return fail(c, RT_ERR_BAD_ARG, "bad spp / sample range / max_depth");
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    const bool accel = c->accel == 1;
+    const bool accel = c->accel == 1, ref = c->arith == RT_ARITH_REFERENCE;
+    if (ref && accel) return fail(c, RT_ERR_UNSUPPORTED, "RT_ARITH_REFERENCE renders by brute force only (RT_OPT_ACCEL must be RT_ACCEL_NONE)");
     const HostScene* Hp = nullptr; DevScene D;
     HostScene na_H;
     unsigned long long* counters = c->d_counters;
@@ -929,7 +937,7 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     PathArgs A{};
     A.width = width; A.height = height; A.sample_begin = s0; A.sample_end = s1; A.max_depth = p->max_depth;
     A.jitter = p->spp > 1; A.seed = p->seed; A.t_min = p->t_min; A.t_min_pos = p->t_min > 0.0f ? p->t_min : 1.401298464e-45f; A.t_max = p->t_max;
-    A.debug_flags = c->debug_flags;
+    A.debug_flags = c->debug_flags; A.ref_rays = ref ? 1 : 0;
     // camera code costs about as much as testing 20 primitives: with few primitives wait for a batch of idle lanes,
     // with many refill every idle lane at once (measured: tools/sweep_regen.py, tools/sweep_regen_stress.py)
     A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : ((accel || scene->n_prims >= 128) ? 1 : 16);
@@ -954,8 +962,8 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
             colours_ok = colours_ok && v >= 0.0f && v <= (scene->materials[m].type == RT_MAT_LIGHT ? 1e6f : 1.0f);
         }
     const bool lds_fit = (size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES;
-    A.queue = (((pk && pk[0] == 'q') || (c->debug_flags & 256)) && !noalloc && !accel && !(c->debug_flags & (2 | 4)) && lds_fit && colours_ok) ? 1 : 0;
-    A.items = (!A.queue && !accel && lds_fit && colours_ok && !(pk && pk[0] == 'r') && !(c->debug_flags & 512) && n_samples > 0) ? 1 : 0;
+    A.queue = (((pk && pk[0] == 'q') || (c->debug_flags & 256)) && !noalloc && !accel && !ref && !(c->debug_flags & (2 | 4)) && lds_fit && colours_ok) ? 1 : 0;
+    A.items = (!A.queue && !accel && !ref && lds_fit && colours_ok && !(pk && pk[0] == 'r') && !(c->debug_flags & 512) && n_samples > 0) ? 1 : 0;
     // The outcome-sorted form (path_sorted_body: the workgroup sorts its paths by what the query found, every wave runs one kind of
     // work): RT_MI355_PATH=s or debug flag 2048; same eligibility as the item form, blob + exchange buffers within 64 KB of LDS.
     A.sorted = 0;
@@ -1006,7 +1014,7 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     c->jit_note.clear();
     if (!noalloc && !accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && lds_fit &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
-        jit = jit_path_kernel(p->variant, H.slots, H.sruns, p->t_min, p->t_max, A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : A.sorted ? RT_FORM_SORTED : RT_FORM_REGEN, c->jit_note);
+        jit = jit_path_kernel(p->variant, H.slots, H.sruns, p->t_min, p->t_max, A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : A.sorted ? RT_FORM_SORTED : ref ? (RT_FORM_REGEN | RT_FORM_REF) : RT_FORM_REGEN, c->jit_note);
     if (noalloc) c->jit_note = "allocation-free entry point: generic kernel";
     if ((rc = begin_timed(c, st, counters))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
     c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));
@@ -1127,7 +1135,7 @@ static int32_t path_accumulate_group(rt_ctx* c, const rt_scene* scene, const rt_
     for (int i = 0; i < n; ++i) {                       // fan out
         rt_ctx* d = i ? c->peers[i - 1] : c;
         if ((rc = check_ctx(d))) return fail(c, rc, "device group: " + d->err);
-        d->debug_flags = c->debug_flags; d->accel = c->accel; d->regen_threshold_override = c->regen_threshold_override;
+        d->debug_flags = c->debug_flags; d->accel = c->accel; d->arith = c->arith; d->regen_threshold_override = c->regen_threshold_override;
         if (hipError_t e = d->accum.reserve(bytes)) return fail(c, RT_ERR_HIP, std::string("device group: accumulator: ") + hipGetErrorString(e));
         rt_path_params q = *pp;
         share_of(s0, s1, i, n, q.sample_begin, q.sample_end);

@@ -77,6 +77,11 @@ enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLAN
 // r = 10: +8e-7 vs -1.1e-4 - so the refined root is used from r/tMin = 3e4 up (03: the ground sphere only; 04 and the stress
 // scene: none).
 #define RT_BIG_SPHERE_RATIO 30000.0f
+// REF (template parameter of the path kernels' device code, default RT_REF_RAYS): the reference's arithmetic for rays and spheres (see strict_sphere_roots);
+// a scene-specialised build for RT_ARITH_REFERENCE defines RT_REF_RAYS true before this header (rt_jit.hip).
+#ifndef RT_REF_RAYS
+#define RT_REF_RAYS false
+#endif
 __device__ __host__ inline bool is_sphere_type(int t) { return t == PRIM_SPHERE || t == PRIM_SPHERE_BIG; }
 __device__ __host__ inline bool is_aaplane_type(int t) { return t >= PRIM_AAPLANE_X && t <= PRIM_AAPLANE_Z; }
 __device__ __host__ inline bool is_strict_type(int t) { return t >= PRIM_PLANE_STRICT; }
@@ -208,6 +213,32 @@ __device__ __forceinline__ f3 strict_dir(f3 d) {
     const float len = sqrtf((d.x * d.x) + (d.y * d.y) + (d.z * d.z));
     return len > 0.0f ? F3(d.x / len, d.y / len, d.z / len) : F3(0.0f, 0.0f, 0.0f);
 }
+// Ray::intersectsSphere in its own operation order (Common/Ray.hpp:105-121), halved: a = d.d, bh = -b/2 = -(d.oc), c = oc.oc - r*r, dq = disc/4 = bh*bh - a*c,
+// roots (bh -+ sqrt(dq))/a: the reference's numbers exactly (scaling by 2 and 4 is exact in binary floating point).  Why the order matters: c cancels from terms of size
+// |oc|^2 to (nearly) nothing for a ray that starts ON the sphere, b*b - 4ac from terms of size |oc|^2 to r^2, so the rounding of the individual products decides
+// whether a path re-hits the surface it leaves ("acne" at tMin) - and how often it does is part of the image the reference renders.  Two tiers:
+//  - strict_sphere_coeff (the fast kernels, PRIM_SPHERE_BIG slots): the coefficients in the reference's order with a taken as 1, a correctly rounded root.  Enough for
+//    a HUGE sphere (r >> tMin; 03's ground): there the cancellation inside c dominates (fuzz scenes on the ground sphere seen from other cameras: scene queries per
+//    sample off by up to -1.3 % with the fused form, within +-3e-4 with this one; tools/fuzz_path.py, profiles/r03_path_fuzz.txt).
+//  - strict_sphere_roots (reference arithmetic, RT_OPT_ARITHMETIC = RT_ARITH_REFERENCE: every sphere): a = d.d as the reference has it and true divisions.  Needed for
+//    small spheres FAR from the ray's origin (|oc| >> r): |d|^2 is 1 to a few 1e-7 only and 4ac is of size |oc|^2, so a's last bits are as large as the noise.  It
+//    only makes sense with the ray directions normalised as Ray's constructor does and the hit point rounded as the reference rounds it (REF in rt_path_device.h).
+__device__ __forceinline__ void strict_sphere_coeff(f3 centre, float r2, f3 o, f3 d, float& bh, float& dq) {
+    const f3 oc = F3(o.x - centre.x, o.y - centre.y, o.z - centre.z);
+    bh = -((d.x * oc.x + d.y * oc.y) + d.z * oc.z);
+    const float c = ((oc.x * oc.x + oc.y * oc.y) + oc.z * oc.z) - r2;
+    dq = bh * bh - c;
+}
+__device__ __forceinline__ void strict_sphere_roots(f3 centre, float r2, f3 o, f3 d, float& t1, float& t2) {
+    const f3 oc = F3(o.x - centre.x, o.y - centre.y, o.z - centre.z);
+    const float a = (d.x * d.x + d.y * d.y) + d.z * d.z;
+    const float bh = -((d.x * oc.x + d.y * oc.y) + d.z * oc.z);
+    const float c = ((oc.x * oc.x + oc.y * oc.y) + oc.z * oc.z) - r2;
+    const float s = sqrt_refined(bh * bh - a * c);      // NaN when the line misses: fails every compare
+    t1 = (bh - s) / a; t2 = (bh + s) / a;
+}
+// origin + direction * t as the reference rounds it (product, then sum; Common/Ray.hpp, the hit records of the scene elements)
+__device__ __forceinline__ f3 strict_point(f3 o, f3 d, float t) { return F3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t); }
 // Ray::intersectsPlane (Common/Ray.hpp:223-249).  Slot: G = (n, -), A = (p0, 0).
 __device__ __forceinline__ bool strict_plane(f3 n, f3 p0, f3 o, f3 d, float tminp, float& t) {
     const float dn = (d.x * n.x) + (d.y * n.y) + (d.z * n.z);
@@ -266,7 +297,7 @@ __device__ __forceinline__ bool strict_slot(const SceneMem<LDS> M, int type, uin
 // EARLY (scenes of thousands of primitives, k_path_tiled): a wave skips the rest of a test that none of its lanes can pass -
 // a sphere whose discriminant is negative in every lane (its roots would be NaN and fail every compare), a rectangle or
 // triangle whose (padded) bounding sphere the ray's line misses in every lane.  Exact, and with small primitives the common case.
-template <bool LDS, bool PACKED = false, bool EARLY = false>
+template <bool LDS, bool PACKED = false, bool EARLY = false, bool REF = RT_REF_RAYS>
 __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
                                                  f3 o, f3 d, f3 inv_d, float tmin, float tminp, float& closest, uint32_t& best,
                                                  unsigned long long pack0 = 0ULL, unsigned long long pack1 = 0ULL) {
@@ -291,11 +322,11 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
             // the element wins, the distance stays.  disc < 0 gives NaN roots, which fail every compare.
 #define RT_SPHERE_DISC(G, B, DISC) f3 co_ = F3(G) - o; B = dot(d, co_); \
                 DISC = fmaf(B, B, -fmaf(co_.z, co_.z, fmaf(co_.y, co_.y, fmaf(co_.x, co_.x, -(G).w))))
-#define RT_SPHERE_ROOTS(B, DISC, Q) { float s = big ? sqrt_refined(DISC) : sqrt_fast(DISC); float t1 = (B) - s, t2 = (B) + s; \
-                bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; bool ge = tc >= tmin, le = tc <= closest; \
+#define RT_SPHERE_TAKE(T1, T2, Q) { bool near_behind = (T1) < tmin; float tc = near_behind ? (T2) : (T1); bool ge = tc >= tmin, le = tc <= closest; \
                 closest = (ge & le) ? tc : closest; best = (ge & (near_behind | le)) ? (Q) : best; }
+#define RT_SPHERE_ROOTS(B, DISC, Q) { float s = big ? sqrt_refined(DISC) : sqrt_fast(DISC); float t1 = (B) - s, t2 = (B) + s; RT_SPHERE_TAKE(t1, t2, Q) }
             int i = 0;
-            if (EARLY) {   // four spheres per early-out decision: a quarter of the branches, independent discriminants overlap
+            if (EARLY && !big) {   // four spheres per early-out decision: a quarter of the branches, independent discriminants overlap
                 for (; i + 3 < count; i += 4, q += 4 * SLOT_BYTES) {
                     float4 g0 = M.ld4(q), g1 = M.ld4(q + SLOT_BYTES), g2 = M.ld4(q + 2 * SLOT_BYTES), g3 = M.ld4(q + 3 * SLOT_BYTES);
                     float b0, d0, b1, d1, b2, d2, b3, d3;
@@ -313,13 +344,20 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
             }
             for (; i < count; ++i, q += SLOT_BYTES) {
                 float4 g = M.ld4(q);
+                if (REF && big) {
+                    float t1, t2; strict_sphere_roots(F3(g), g.w, o, d, t1, t2);
+                    RT_SPHERE_TAKE(t1, t2, q)
+                    continue;
+                }
                 float b, disc;
-                { RT_SPHERE_DISC(g, b, disc); }
+                if (big) strict_sphere_coeff(F3(g), g.w, o, d, b, disc);
+                else { RT_SPHERE_DISC(g, b, disc); }
                 if (EARLY && __builtin_amdgcn_ballot_w64(disc >= 0.0f) == 0ULL) continue;
                 RT_SPHERE_ROOTS(b, disc, q)
             }
 #undef RT_SPHERE_DISC
 #undef RT_SPHERE_ROOTS
+#undef RT_SPHERE_TAKE
         } else if (is_aaplane_type(type)) {
             // Ray::intersectsPlane (Ray.hpp:223-249) for a normal +-e_axis: n.p0 - n.o = +-(p0_a - o_a), d.n = +-d_a, so
             // t = (p0_a - o_a) * (1/d_a), 1/d shared by all such planes of the ray.  tminp = max(tMin, smallest positive
@@ -340,7 +378,7 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
             }
         } else if (is_strict_type(type)) {   // coplanar with a slot of another kind: the reference's own operation sequence (see PRIM_*_STRICT)
             const uint32_t step = type == PRIM_PLANE_STRICT ? SLOT_BYTES : 2 * SLOT_BYTES;
-            const f3 ds = strict_dir(d);
+            const f3 ds = REF ? d : strict_dir(d);      // REF: the ray already holds the direction as the reference does
             for (int i = 0; i < count; ++i, q += step) {
                 float t;
                 const bool hit = strict_slot<LDS>(M, type, q, o, ds, tminp, t) & (t <= closest);
@@ -376,12 +414,12 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
 }
 // The whole scene in one go: q = SceneMem address of the first slot.  Returns the address of the winning slot (0 = miss:
 // address 0 is the runs section, or the first bytes of LDS, never a slot) and its distance.
-template <bool LDS, bool EARLY = false>
+template <bool LDS, bool EARLY = false, bool REF = RT_REF_RAYS>
 __device__ __forceinline__ uint32_t closest_hit_slots(const SceneMem<LDS> M, const int4* __restrict__ runs, int n_runs, uint32_t q,
                                                       f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {
     uint32_t best = 0U;
     float closest = tmax;
-    closest_hit_runs<LDS, false, EARLY>(M, runs, n_runs, q, o, d, F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)), tmin, tminp, closest, best);
+    closest_hit_runs<LDS, false, EARLY, REF>(M, runs, n_runs, q, o, d, F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)), tmin, tminp, closest, best);
     t_out = closest;
     return best;
 }

@@ -46,6 +46,18 @@ std::string lit(float v) {   // exact: hexadecimal floating literal
     return b;
 }
 std::string v3(const float4& g) { return "F3(" + lit(g.x) + ", " + lit(g.y) + ", " + lit(g.z) + ")"; }
+// opens a block and leaves the roots t1 <= t2 of a sphere slot g = (centre, r*r) (NaN when the line misses);
+// PRIM_SPHERE_BIG: the coefficients in the reference's own operation order and a correctly rounded root (rt_device.h: strict_sphere_coeff; reference arithmetic: strict_sphere_roots)
+thread_local bool g_gen_ref = false;      // the source being generated is for RT_ARITH_REFERENCE
+std::string sphere_root_source(int type, const float4& g) {
+    if (type == PRIM_SPHERE_BIG && g_gen_ref)
+        return "    { float t1, t2; strict_sphere_roots(" + v3(g) + ", " + lit(g.w) + ", o, d, t1, t2);";
+    if (type == PRIM_SPHERE_BIG)
+        return "    { float b, dq; strict_sphere_coeff(" + v3(g) + ", " + lit(g.w) + ", o, d, b, dq); float s = sqrt_refined(dq); float t1 = b - s, t2 = b + s;";
+    return "    { f3 co = " + v3(g) + " - o; float b = dot(d, co);\n"
+           "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g.w) + ")));\n"
+           "      float s = sqrt_fast(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;";
+}
 
 
 // Literal-coefficient sums with the terms whose coefficient is exactly 0 left out: in the generic loops they are multiplied
@@ -83,7 +95,7 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
     std::string s;
     s += "namespace rt {\n__device__ __forceinline__ uint32_t closest_hit_jit(f3 o, f3 d, float tmin, float tminp, float tmax, float& t_out) {\n";
     s += "    uint32_t best = 0U;\n    float closest = tmax;\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d; (void)tmin; (void)tminp;\n";
-    for (const int4& run : sruns) if (is_strict_type(run.x)) { s += "    const f3 ds = strict_dir(d);\n"; break; }
+    for (const int4& run : sruns) if (is_strict_type(run.x)) { s += g_gen_ref ? "    const f3 ds = d;\n" : "    const f3 ds = strict_dir(d);\n"; break; }
     size_t q = 0;   // float4 index into slots
     for (const int4& run : sruns) {
         for (int i = 0; i < run.z; ++i) {
@@ -91,9 +103,7 @@ std::string gen_closest_hit(const std::vector<float4>& slots, const std::vector<
             const std::string K = std::to_string(q * 16 + SLOT_BYTES) + "U";
             const std::string take = "closest = hit ? t : closest; best = hit ? " + K + " : best; }\n";
             if (is_sphere_type(run.x)) {
-                s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
-                s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
-                s += std::string("      float s = ") + (run.x == PRIM_SPHERE_BIG ? "sqrt_refined" : "sqrt_fast") + "(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;\n";
+                s += sphere_root_source(run.x, g[0]) + "\n";
                 s += "      bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; bool ge = tc >= tmin, le = tc <= closest;\n";
                 s += "      closest = (ge & le) ? tc : closest; best = (ge & (near_behind | le)) ? " + K + " : best; }\n";
             } else if (is_aaplane_type(run.x)) {
@@ -126,14 +136,12 @@ std::string gen_any_hit(const std::vector<float4>& slots, const std::vector<int4
     // changes nothing (that element occludes), and the sphere rule "origin inside, far root beyond tMax" occludes in both.
     s += "__device__ __forceinline__ bool any_hit_jit(f3 o, f3 d, float tmin, float tminp, float tmax) {\n";
     s += "    bool occ = false;\n    const f3 inv_d = F3(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));\n    (void)inv_d; (void)tmin; (void)tminp;\n";
-    for (const int4& run : sruns) if (is_strict_type(run.x)) { s += "    const f3 ds = strict_dir(d);\n"; break; }
+    for (const int4& run : sruns) if (is_strict_type(run.x)) { s += g_gen_ref ? "    const f3 ds = d;\n" : "    const f3 ds = strict_dir(d);\n"; break; }
     for (const int4& run : sruns) {
         for (int i = 0; i < run.z; ++i) {
             const float4* g = &slots[q];
             if (is_sphere_type(run.x)) {
-                s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
-                s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
-                s += std::string("      float s = ") + (run.x == PRIM_SPHERE_BIG ? "sqrt_refined" : "sqrt_fast") + "(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;\n";
+                s += sphere_root_source(run.x, g[0]) + "\n";
                 s += "      bool near_behind = t1 < tmin; float tc = near_behind ? t2 : t1; occ |= (tc >= tmin) & (near_behind | (tc <= tmax)); }\n";
             } else if (is_aaplane_type(run.x)) {
                 const char* ax = run.x == PRIM_AAPLANE_X ? "x" : run.x == PRIM_AAPLANE_Y ? "y" : "z";
@@ -258,15 +266,13 @@ std::string gen_closest_hit_v2(const std::vector<float4>& slots, const std::vect
             if (skip && ((is_sphere_type(run.x) && strchr(skip, 's')) || (is_aaplane_type(run.x) && strchr(skip, 'a')) || ((run.x == PRIM_RECT || run.x == PRIM_TRI) && strchr(skip, 'r')))) {
                 q += is_wide_type(run.x) ? 8 : 4; continue; }
             if (is_sphere_type(run.x)) {
-                s += "    { f3 co = " + v3(g[0]) + " - o; float b = dot(d, co);\n";
-                s += "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g[0].w) + ")));\n";
-                s += std::string("      float s = ") + (run.x == PRIM_SPHERE_BIG ? "sqrt_refined" : "sqrt_fast") + "(fmaf(b, b, -c));\n";
+                s += sphere_root_source(run.x, g[0]) + "\n";
                 if (sphere_interior_is_empty(slots, sruns, q, tmin, tmax)) {
-                    s += "      float t1 = b - s; uint32_t k = __float_as_uint(t1 < " + lit(tmin) + " ? b + s : t1) - " + C + ";\n";
+                    s += "      uint32_t k = __float_as_uint(t1 < " + lit(tmin) + " ? t2 : t1) - " + C + ";\n";
                     s += "     " + take(K);
                     q += 4; continue;
                 }
-                s += "      uint32_t k1 = __float_as_uint(b - s) - " + C + ", k2 = __float_as_uint(b + s) - " + C + "; uint32_t k = k1 < k2 ? k1 : k2;\n";
+                s += "      uint32_t k1 = __float_as_uint(t1) - " + C + ", k2 = __float_as_uint(t2) - " + C + "; uint32_t k = k1 < k2 ? k1 : k2;\n";
                 // the tMax rule: near root behind tMin, far root ahead (finite) but not accepted: the element wins, the distance stays
                     s += "      bool a = k <= ck; bool w = a | ((k1 > " + hex(J.vmax) + ") & (k2 <= " + hex(J.vmax) + ")); ck = a ? k : ck; best = w ? " + K + " : best; }\n";
             } else if (is_aaplane_type(run.x)) {
@@ -324,6 +330,9 @@ bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector
 hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note, hipFunction_t* second,
                               const std::vector<int4>* wruns, const std::vector<float4>* wgeom) {
     if (second) *second = nullptr;
+    const bool ref = (form & RT_FORM_REF) != 0;
+    form &= 7;
+    if (ref && form != RT_FORM_REGEN) { note = "reference arithmetic: per-lane regeneration only"; return nullptr; }
     const bool whitted = variant == RT_JIT_WHITTED_SOFT || variant == RT_JIT_WHITTED_HARD;
     size_t n_prims = 0;
     for (const int4& r : sruns) n_prims += (size_t)r.z;
@@ -338,6 +347,8 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
             else cur += *p;
         }
     }
+    if (ref) defs += "#define RT_REF_RAYS true\n";
+    g_gen_ref = ref;
     std::string src = defs + std::string("#define RT_JIT_SCENE 1\ntypedef unsigned int uint32_t; typedef unsigned char uint8_t; typedef unsigned long long uint64_t; typedef unsigned long uintptr_t;\n") + kSrcArgs + "\n" + kSrcDevice + "\n";
     // generation 1 (float compares) is the default: on MI355X it measured 2 % faster than generation 2 (unsigned keys) although
     // the latter has the cheaper instruction mix on paper; RT_MI355_JIT_GEN=2 selects generation 2 (same image, bit for bit)

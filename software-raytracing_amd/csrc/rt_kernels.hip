@@ -14,13 +14,14 @@ namespace rt {
 // =================================================================================================
 // K3/K4: path tracing (device code in rt_path_device.h).
 // =================================================================================================
-template <int VARIANT, bool LDS, bool EARLY = false>
+// REF: the reference's arithmetic for rays and spheres (RT_OPT_ARITHMETIC = RT_ARITH_REFERENCE; rt_device.h strict_sphere_roots)
+template <int VARIANT, bool LDS, bool EARLY = false, bool REF = false>
 __global__ __launch_bounds__(256) void k_path(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
-    path_body<VARIANT, LDS, EARLY>(SD, A, out, counters);
+    path_body<VARIANT, LDS, EARLY, REF>(SD, A, out, counters);
 }
-template <int VARIANT>
+template <int VARIANT, bool REF = false>
 __global__ __launch_bounds__(256) void k_path_tiled(DevScene SD, PathArgs A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
-    path_tiled_body<VARIANT>(SD, A, out, counters);
+    path_tiled_body<VARIANT, REF>(SD, A, out, counters);
 }
 
 // Queue form (rt_path_device.h): ray-queue compaction through LDS inside the workgroup.
@@ -72,6 +73,12 @@ static void launch_path_v(const DevScene& S, const PathArgs& A, float4* out, int
     if (queue && !(A.debug_flags & 2)) {
         if (S.slot_bytes > 64 * 64) hipLaunchKernelGGL((k_path_q<VARIANT, true, true>), grid, dim3(256), bytes + RT_Q_WS_BYTES, st, S, A, out, counters);
         else                        hipLaunchKernelGGL((k_path_q<VARIANT, true>), grid, dim3(256), bytes + RT_Q_WS_BYTES, st, S, A, out, counters);
+        return;
+    }
+    if (A.ref_rays) {   // reference arithmetic: one lane per pixel; LDS-resident (with early-outs from 64 slots up) or tiled
+        if (bytes > RT_LDS_SCENE_MAX_BYTES) hipLaunchKernelGGL((k_path_tiled<VARIANT, true>), grid, dim3(256), RT_TILE_BYTES + SLOT_BYTES, st, S, A, out, counters);
+        else if (S.slot_bytes > 64 * 64)    hipLaunchKernelGGL((k_path<VARIANT, true, true, true>), grid, dim3(256), bytes, st, S, A, out, counters);
+        else                                hipLaunchKernelGGL((k_path<VARIANT, true, false, true>), grid, dim3(256), bytes, st, S, A, out, counters);
         return;
     }
     if (A.debug_flags & 2)                   hipLaunchKernelGGL((k_path<VARIANT, false>), grid, dim3(256), 0, st, S, A, out, counters);   // A/B reference: scalar loads from the global blob

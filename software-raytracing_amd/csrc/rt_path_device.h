@@ -31,6 +31,8 @@ __device__ __forceinline__ PathLane lane_init(int s_next) {
 }
 
 // Path regeneration: idle lanes ('want') take the next sample of their pixel once enough of the wave is idle.
+// REF: the reference's arithmetic for rays (RT_ARITH_REFERENCE; rt_device.h strict_sphere_roots) - directions normalised as Ray's constructor normalises them.
+template <bool REF = RT_REF_RAYS>
 __device__ __forceinline__ void regenerate(const PathArgs& A, int px, int py, uint32_t pkey, bool want, unsigned long long m_want, unsigned long long m_alive, PathLane& L) {
     if (m_want && (m_alive == 0ULL || __popcll(m_want) >= A.regen_threshold)) {
         if (want) {   // Render: one primary ray (03 Main.cpp:331-341, 04 Main.cpp:359-369)
@@ -42,7 +44,7 @@ __device__ __forceinline__ void regenerate(const PathArgs& A, int px, int py, ui
             float y = -fmaf((float)py + by, A.inv_h2, -1.0f) * A.ky;
             f3 v = F3(x, y, -1.0f);
             const f3 rv = F3(dot(F3(A.r[0], A.r[1], A.r[2]), v), dot(F3(A.r[3], A.r[4], A.r[5]), v), dot(F3(A.r[6], A.r[7], A.r[8]), v));
-            L.d = rv * rsq_fast(dot(rv, rv));      // Normalize; |rv| >= 1 (v.z = -1, r a rotation), so its zero-vector guard cannot fire
+            L.d = REF ? strict_dir(rv) : rv * rsq_fast(dot(rv, rv));      // Normalize; |rv| >= 1 (v.z = -1, r a rotation), so its zero-vector guard cannot fire
             L.o = F3(A.px, A.py, A.pz);
             L.thr = F3(1, 1, 1);
             L.depth = 0;
@@ -76,7 +78,7 @@ __device__ __forceinline__ void add_radiance(PathLane& L, f3 v) {
 
 // One bounce after the scene query: miss / emit / scatter (TraceTay of 03 Main.cpp:392-435, 04 Main.cpp:447-502).
 // hit = SceneMem address of the winning slot (unused when miss), t = its distance.
-template <int VARIANT, bool LDS, bool DEPOSIT = false>
+template <int VARIANT, bool LDS, bool DEPOSIT = false, bool REF = RT_REF_RAYS>
 __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, uint32_t mats0, bool miss, uint32_t hit, float t, PathLane& L) {
     if (miss) {
         if (VARIANT == 3) {   // sky: Mix(white, (0.5,0.7,1), 0.5*(d.y+1)) (03 Main.cpp:430-432)
@@ -88,7 +90,7 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
         // hit record (03 Sphere.hpp:57-73; 04 Scene/Sphere.hpp:58-74, Plane.hpp:55-66, Rectangle.hpp:79-92), one
         // formula for every primitive type (slot layout, rt_device.h): n = (p - c)*k + m, turned against the ray
         float4 sa = M.ld4(hit + SLOT_A), sb = M.ld4(hit + SLOT_B), sc = M.ld4(hit + SLOT_C);
-        L.o = madd(L.d, t, L.o);                       // the hit point is the next origin; nothing below needs the old one
+        L.o = REF ? strict_point(L.o, L.d, t) : madd(L.d, t, L.o);      // the hit point is the next origin; nothing below needs the old one
         f3 pc = L.o - F3(sa);
         // spheres: Normalize(p - c) (k = +-1; also right when the hit was reported at tMax, off the surface); others: k = 0
         float k = sa.w * rsq_fast(fmaf(pc.z, pc.z, fmaf(pc.y, pc.y, fmaf(pc.x, pc.x, 1e-30f))));
@@ -164,7 +166,7 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
                     if (degenerate) nd = normalize(nd);
                 }
             }
-            L.d = nd;   // unit: n is unit (slot layout), Reflect/Refract keep the length, the sampled direction is unit by construction
+            L.d = REF ? strict_dir(nd) : nd;   // unit (REF: as Ray's constructor leaves it, Common/Ray.hpp:33-34): n is unit (slot layout), Reflect/Refract keep the length, the sampled direction is unit by construction
             if (mtype != MAT_DIELECTRIC) {
                 f3 att = F3(m0);
                 if (VARIANT == 4) att = att * fmaxf(dot(L.d, n), 0.0f);      // 04 Diffuse.hpp:77-78, Metal.hpp:83-84
@@ -181,7 +183,7 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
 // Small scenes (blob <= 48 KB, LDS = true): every block stages the whole blob in LDS once.  LDS = false: the blob is
 // read from global memory with scalar loads (debug flag 2; A/B reference for the other two kernels).
 // EARLY: wave-level early-outs in the primitive tests (rt_device.h), for scenes of many small primitives.
-template <int VARIANT, bool LDS, bool EARLY = false>
+template <int VARIANT, bool LDS, bool EARLY = false, bool REF = RT_REF_RAYS>
 __device__ __forceinline__ void path_body(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 smem[];
     const char* base = reinterpret_cast<const char*>(SD.blob);
@@ -206,7 +208,7 @@ __device__ __forceinline__ void path_body(const DevScene& SD, const PathArgs& A,
     for (;;) {
         RT_WAVE_STATE(L, s_end);
         if ((m_want | m_alive) == 0ULL) break;
-        regenerate(A, px, py, pkey, want, m_want, m_alive, L);
+        regenerate<REF>(A, px, py, pkey, want, m_want, m_alive, L);
         if (L.alive) {
             // TraceTay: one scene query (03 Main.cpp:392, 04 Main.cpp:447)
             ++L.rays;
@@ -217,10 +219,10 @@ __device__ __forceinline__ void path_body(const DevScene& SD, const PathArgs& A,
             const bool miss = k == 0U;
             (void)runs;
 #else
-            uint32_t hit = closest_hit_slots<LDS, EARLY>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
+            uint32_t hit = closest_hit_slots<LDS, EARLY, REF>(M, runs, SD.n_sruns, slots0, L.o, L.d, A.t_min, A.t_min_pos, A.t_max, t);
             const bool miss = hit == 0U;
 #endif
-            shade<VARIANT, LDS>(M, A, mats0, miss, hit, t, L);
+            shade<VARIANT, LDS, false, REF>(M, A, mats0, miss, hit, t, L);
         }
     }
     if (inside) {
@@ -712,7 +714,7 @@ __device__ __forceinline__ void path_sorted_body(const DevScene& SD, const PathA
 // stage through LDS together (one global read per block instead of one per wave, and VGPR operands for the tests), so
 // the bounce loop runs in lockstep per BLOCK: regenerate per wave, then every chunk between two barriers, then shade.
 // The winner is remembered as a blob offset (its chunk is gone from LDS by shading time) and shaded from global memory.
-template <int VARIANT>
+template <int VARIANT, bool REF = RT_REF_RAYS>
 __device__ __forceinline__ void path_tiled_body(const DevScene& SD, const PathArgs& A, float4* __restrict__ out, unsigned long long* __restrict__ counters) {
     extern __shared__ float4 smem[];
     const int4* __restrict__ runs = reinterpret_cast<const int4*>(SD.blob + SD.off_sruns);
@@ -736,7 +738,7 @@ __device__ __forceinline__ void path_tiled_body(const DevScene& SD, const PathAr
     for (;;) {
         {
             RT_WAVE_STATE(L, s_end);
-            regenerate(A, px, py, pkey, want, m_want, m_alive, L);
+            regenerate<REF>(A, px, py, pkey, want, m_want, m_alive, L);
         }
         if (!__syncthreads_or(L.alive)) break;      // block-uniform: a finished wave keeps staging chunks for the others
         float closest = A.t_max;
@@ -750,13 +752,13 @@ __device__ __forceinline__ void path_tiled_body(const DevScene& SD, const PathAr
             __syncthreads();
             if (L.alive) {
                 uint32_t b = 0U;
-                closest_hit_runs<true, false, true>(T, runs + ch.z, ch.w, tile0, L.o, L.d, inv_d, A.t_min, A.t_min_pos, closest, b);
+                closest_hit_runs<true, false, true, REF>(T, runs + ch.z, ch.w, tile0, L.o, L.d, inv_d, A.t_min, A.t_min_pos, closest, b);
                 if (b) best = b - tile0 + (uint32_t)ch.x;
             }
         }
         if (L.alive) {
             ++L.rays;
-            shade<VARIANT, false>(G, A, 0U, best == 0U, best, closest, L);
+            shade<VARIANT, false, false, REF>(G, A, 0U, best == 0U, best, closest, L);
         }
     }
     if (inside) out[(size_t)slice * A.width * A.height + pixel] = make_float4(L.acc.x, L.acc.y, L.acc.z, (A.debug_flags & 4) ? (float)L.rays : (float)L.n_started);

@@ -36,6 +36,7 @@ int main(int argc, char* argv[]) {
 
         rtbackend::context();   // device / library initialisation is not part of the render time reported below
         if (opt.bvh) rtbackend::check(rt_set_option(rtbackend::context(), RT_OPT_ACCEL, RT_ACCEL_BVH));
+        if (opt.reference_arithmetic) rtbackend::check(rt_set_option(rtbackend::context(), RT_OPT_ARITHMETIC, RT_ARITH_REFERENCE));
         auto renderBeginTime = std::chrono::system_clock::now();
         if (opt.chunk && !opt.present.empty()) {
             // interactive: --chunk samples per pass, every pass presented to --present (the sums stay on the GPU)

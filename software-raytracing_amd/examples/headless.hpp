@@ -17,6 +17,7 @@ struct Options {
     std::string present;                 // frame sink in place of the window: file.bmp (rewritten per frame), a raw B,G,R,x stream file / FIFO, or - (stdout)
     unsigned chunk = 0, stopAfter = 0;   // progressive rendering: samples per pass, stop early (to be resumed)
     bool bvh = false;                    // 03/04: query the scene through the optional BVH (same image, fewer primitive tests)
+    bool reference_arithmetic = false;   // 03/04: RT_ARITH_REFERENCE - rays and spheres in the reference's own floating-point operation sequence (slower)
 };
 
 inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
@@ -29,6 +30,7 @@ inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
             return argv[++i];
         };
         if (std::strcmp(argv[i], "--bvh") == 0) o.bvh = true;
+        else if (std::strcmp(argv[i], "--reference-arithmetic") == 0) o.reference_arithmetic = true;
         else if (const char* v = value("--gpus")) {          // 03/04: a device group over GPUs 0..N-1 (rt_create_multi)
             std::vector<int32_t> ids; for (int k = 0, n = std::atoi(v); k < n; ++k) ids.push_back(k);
             rtbackend::use_devices(ids);
@@ -47,7 +49,7 @@ inline Options ParseOptions(int argc, char* argv[], unsigned defaultSamples) {
         else if (const char* v = value("--checkpoint")) o.checkpoint = v;
         else if (const char* v = value("--chunk")) o.chunk = static_cast<unsigned>(std::atoi(v));
         else if (const char* v = value("--stop-after")) o.stopAfter = static_cast<unsigned>(std::atoi(v));
-        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after --bvh --gpus --devices --present)");
+        else throw std::runtime_error(std::string("ERROR: unknown option ") + argv[i] + " (use --width --height --samples --seed --out --dump-scene --chunk --checkpoint --stop-after --bvh --reference-arithmetic --gpus --devices --present)");
     }
     return o;
 }

@@ -10,6 +10,7 @@ RT_ERR_TOO_LARGE = -5
 
 RT_PRIM_SPHERE, RT_PRIM_PLANE, RT_PRIM_RECT, RT_PRIM_TRIANGLE, RT_PRIM_BOX = 0, 1, 2, 3, 4
 RT_OPT_ACCEL, RT_ACCEL_NONE, RT_ACCEL_BVH = 1, 0, 1
+RT_OPT_ARITHMETIC, RT_ARITH_FAST, RT_ARITH_REFERENCE = 2, 0, 1
 RT_PRIM_FLAG_FLIP_NORMALS = 1
 RT_MAT_PHONG, RT_MAT_DIFFUSE, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_LIGHT = 0, 1, 2, 3, 4
 RT_PATH_SKY, RT_PATH_LIGHTS = 3, 4

@@ -1,0 +1,106 @@
+"""GPU tests of the cases where the last bits of the sphere test decide what a path does next: large spheres seen from
+arbitrary cameras in the default (fast) arithmetic, and RT_OPT_ARITHMETIC = RT_ARITH_REFERENCE for small spheres far from the rays'
+origins.  The oracle is the reference's arithmetic (oracle/rt_oracle.c, pinned by the reference's own headers); equal seeds throughout.
+Found by tools/fuzz_path.py (random scenes); the figures quoted are profiles/r03_path_fuzz.txt's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from rtamd import abi, scenes
+import orc as oracle
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_queries(ctx, s, cam, prm, w, h, flags):
+    ctx.set_debug_flags(flags)
+    try: g = ctx.render_path(s, cam, prm, w, h)
+    finally: ctx.set_debug_flags(0)
+    return g
+
+
+@pytest.mark.parametrize("camera", [((-0.18, 1.51, 1.73), (-16.9, 29.2, 0.0), 88.8), ((1.28, 1.85, 3.0), (-13.9, 36.5, 0.0), 61.8), ((-0.89, 1.34, 2.52), (-15.3, -19.0, 0.0), 53.6)])
+def test_ground_sphere_from_other_cameras_fast_arithmetic(ctx, camera):
+    """03's scene (ground sphere r = 100, tMin = 0.001) seen from cameras that look further across the ground than the reference's.
+    Leaving a sphere of that size, c = oc.oc - r*r cancels from 1e4 to ~1e-3 and decides whether the ray re-hits the ground above
+    tMin; the reference does that in about one bounce of a hundred there.  With the coefficients fused (round 2) HIP traced up to
+    1.3 % FEWER queries than the oracle from these cameras; PRIM_SPHERE_BIG slots now compute them in the reference's operation
+    order (rt_device.h strict_sphere_coeff): within +-3e-4, generic and specialised kernel on the same paths."""
+    pos, ori, fov = camera
+    s, _, _ = scenes.scene03(64, seed=5)
+    cam = scenes.camera(fov, pos, ori)
+    prm = scenes.path_params(abi.RT_PATH_SKY, 64, seed=5)
+    o = oracle.render_path(s, cam, prm, 192, 128, threads=8)
+    a = _rel_queries(ctx, s, cam, prm, 192, 128, 8)
+    b = _rel_queries(ctx, s, cam, prm, 192, 128, 16)
+    assert ctx.last_path_kernel()[0] == 2
+    assert a["rays"] == b["rays"] and np.array_equal(a["rgb"], b["rgb"])
+    assert abs(a["rays"] / o["rays"] - 1.0) <= 1e-3, a["rays"] / o["rays"] - 1.0
+    mo = (o["sum"] / 64).reshape(-1, 3).mean(axis=0)
+    assert np.abs(a["rgb"].reshape(-1, 3).mean(axis=0) / mo - 1.0).max() <= 5e-4
+
+
+def _far_small_spheres(n=600):
+    """Diffuse and metal spheres of radius 0.3-1.5 up to 160 units away, nothing else (tools/bias_scan_stress.py: 'no mesh, no plane')."""
+    g = scenes._PCG32(0x5EED); s = scenes.Scene()
+    for i in range(n):
+        c = (g.u(-60, 60), g.u(-4, 40), g.u(-160, -10)); r = g.u(0.3, 1.5)
+        alb = (g.u(0.2, 0.9), g.u(0.2, 0.9), g.u(0.2, 0.9))
+        s.sphere(s.metal(alb, 0.2) if i % 2 else s.diffuse(alb), c, r)
+    return s, scenes.camera(60.0, (0, 5, 20), (-10, 0, 0))
+
+
+def test_reference_arithmetic_for_far_small_spheres(ctx):
+    """Small spheres far from where the rays start, 03 estimator at tMin = 0.001: b*b - 4ac cancels from |oc|^2 ~ 1e4 to r^2 ~ 1, so
+    the hit point lies up to ~1e-3 inside or outside the surface and the next ray re-hits it or not by rounding.  The fast arithmetic
+    traces +0.5...0.9 % more queries than the reference's (documented); RT_ARITH_REFERENCE - directions normalised as
+    Ray's constructor does, Ray::intersectsSphere's own operations with a = d.d, hit points rounded as there - follows it to a few 1e-4.
+    Also: the option is refused together with the BVH, and switching it back restores the fast kernels' paths."""
+    s, cam = _far_small_spheres()
+    prm = scenes.path_params(abi.RT_PATH_SKY, 64, max_depth=8, seed=3)
+    w, h = 196, 140
+    o = oracle.render_path(s, cam, prm, w, h, threads=8)
+    fast = ctx.render_path(s, cam, prm, w, h)
+    ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_REFERENCE)
+    try:
+        ref = ctx.render_path(s, cam, prm, w, h)
+        assert ctx.last_path_form()[0] == 0                      # one lane per pixel
+        ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_BVH)
+        with pytest.raises(RuntimeError, match="brute force"):
+            ctx.render_path(s, cam, prm, w, h)
+        ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_NONE)
+    finally:
+        ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_NONE); ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_FAST)
+    again = ctx.render_path(s, cam, prm, w, h)
+    assert again["rays"] == fast["rays"] and np.array_equal(again["rgb"], fast["rgb"])
+    assert abs(ref["rays"] / o["rays"] - 1.0) <= 1e-3, ref["rays"] / o["rays"] - 1.0
+    assert 2e-3 <= fast["rays"] / o["rays"] - 1.0 <= 1.5e-2, fast["rays"] / o["rays"] - 1.0      # the documented deviation of the fast arithmetic, pinned
+    mo = (o["sum"] / 64).reshape(-1, 3).mean(axis=0)
+    assert np.abs(ref["rgb"].reshape(-1, 3).mean(axis=0) / mo - 1.0).max() <= 1e-3
+
+
+@pytest.mark.parametrize("which", ["03", "04", "nest"])
+def test_reference_arithmetic_kernel_forms_agree(ctx, which):
+    """RT_ARITH_REFERENCE: the generic kernel, the scene-specialised kernel and (with a scene cut off beyond 48 KB) the tiled kernel
+    trace the same paths, and they are the oracle's to the tolerance of the default arithmetic's own tests."""
+    from conftest import nest_scene
+    if which == "03": s, cam, prm = scenes.scene03(16, seed=4)
+    elif which == "04": s, cam, prm = scenes.scene04(16, seed=4)
+    else:
+        s, cam = nest_scene(); prm = scenes.path_params(abi.RT_PATH_LIGHTS, 16, seed=4)
+    w, h = 160, 120
+    o = oracle.render_path(s, cam, prm, w, h, threads=8)
+    ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_REFERENCE)
+    try:
+        a = _rel_queries(ctx, s, cam, prm, w, h, 8)
+        assert ctx.last_path_kernel()[0] == 1
+        b = _rel_queries(ctx, s, cam, prm, w, h, 16)
+        assert ctx.last_path_kernel()[0] == 2, ctx.last_path_kernel()[1]
+    finally:
+        ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_FAST)
+    assert a["rays"] == b["rays"] and np.array_equal(a["rgb"], b["rgb"])
+    assert abs(a["rays"] / o["rays"] - 1.0) <= (5e-3 if which == "nest" else 5e-4), a["rays"] / o["rays"] - 1.0

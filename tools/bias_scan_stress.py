@@ -6,6 +6,7 @@ import numpy as np
 from rtamd import abi, lib, scenes
 import orc as oracle
 ctx = lib.Context()
+if os.environ.get("FUZZ_ARITH") == "ref": ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_REFERENCE)      # the reference's arithmetic for rays and spheres
 W, H, SPP = 196, 140, 64
 def cmp(tag, s, cam, variant):
     prm = scenes.path_params(variant, SPP, max_depth=8, seed=3)
