@@ -26,14 +26,13 @@ __device__ __forceinline__ void bvh_test(const SceneMem<false> M, uint32_t ref, 
     const int type = (int)(ref & 15U);
     if (is_sphere_type(type)) {
         float4 g = M.ld4(q);
-        float b, s;      // as in closest_hit_runs: same bits
-        if (type == PRIM_SPHERE_BIG) { float dq; strict_sphere_coeff(F3(g), g.w, o, d, b, dq); s = sqrt_refined(dq); }
+        float t1, t2;      // as in closest_hit_runs: same bits
+        if (type == PRIM_SPHERE_BIG) big_sphere_roots(F3(g), g.w, o, d, t1, t2);
         else {
             f3 co = F3(g) - o;
-            b = dot(d, co);
-            s = sqrt_fast(fmaf(b, b, -fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, -g.w)))));
+            const float b = dot(d, co), s = sqrt_fast(fmaf(b, b, -fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, -g.w)))));
+            t1 = b - s; t2 = b + s;
         }
-        float t1 = b - s, t2 = b + s;
         bool near_behind = t1 < tmin;
         float tc = near_behind ? t2 : t1;
         bool ge = tc >= tmin;

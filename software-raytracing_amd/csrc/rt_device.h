@@ -217,17 +217,23 @@ __device__ __forceinline__ f3 strict_dir(f3 d) {
 // roots (bh -+ sqrt(dq))/a: the reference's numbers exactly (scaling by 2 and 4 is exact in binary floating point).  Why the order matters: c cancels from terms of size
 // |oc|^2 to (nearly) nothing for a ray that starts ON the sphere, b*b - 4ac from terms of size |oc|^2 to r^2, so the rounding of the individual products decides
 // whether a path re-hits the surface it leaves ("acne" at tMin) - and how often it does is part of the image the reference renders.  Two tiers:
-//  - strict_sphere_coeff (the fast kernels, PRIM_SPHERE_BIG slots): the coefficients in the reference's order with a taken as 1, a correctly rounded root.  Enough for
-//    a HUGE sphere (r >> tMin; 03's ground): there the cancellation inside c dominates (fuzz scenes on the ground sphere seen from other cameras: scene queries per
-//    sample off by up to -1.3 % with the fused form, within +-3e-4 with this one; tools/fuzz_path.py, profiles/r03_path_fuzz.txt).
+//  - big_sphere_roots (the fast kernels, PRIM_SPHERE_BIG slots: r >> tMin, 03's ground): the coefficients in the reference's order, a = d.d of the kernel's own direction,
+//    a correctly rounded root, the division by a as one fused correction.  The cancellation inside c dominates for a ray that leaves the sphere (fuzz scenes on the
+//    ground sphere seen from other cameras: scene queries per sample off by up to -1.3 % with the fused form, within +-3e-4 with the reference's order), and a matters
+//    for a ray that crosses it INSIDE (a rough metal ground scatters into the sphere): the far root is ~2r, and with a taken as 1 the hit point lies 2r(|d|^2 - 1) ~ 2e-5
+//    off the surface - more than the reference's rounding noise there, so more false self-hits at the next bounce (+0.3 % scene queries; with a: see profiles/r03_path_fuzz.txt).
 //  - strict_sphere_roots (reference arithmetic, RT_OPT_ARITHMETIC = RT_ARITH_REFERENCE: every sphere): a = d.d as the reference has it and true divisions.  Needed for
 //    small spheres FAR from the ray's origin (|oc| >> r): |d|^2 is 1 to a few 1e-7 only and 4ac is of size |oc|^2, so a's last bits are as large as the noise.  It
 //    only makes sense with the ray directions normalised as Ray's constructor does and the hit point rounded as the reference rounds it (REF in rt_path_device.h).
-__device__ __forceinline__ void strict_sphere_coeff(f3 centre, float r2, f3 o, f3 d, float& bh, float& dq) {
+__device__ __forceinline__ void big_sphere_roots(f3 centre, float r2, f3 o, f3 d, float& t1, float& t2) {
     const f3 oc = F3(o.x - centre.x, o.y - centre.y, o.z - centre.z);
-    bh = -((d.x * oc.x + d.y * oc.y) + d.z * oc.z);
+    const float a = (d.x * d.x + d.y * d.y) + d.z * d.z;
+    const float bh = -((d.x * oc.x + d.y * oc.y) + d.z * oc.z);
     const float c = ((oc.x * oc.x + oc.y * oc.y) + oc.z * oc.z) - r2;
-    dq = bh * bh - c;
+    const float s = sqrt_refined(bh * bh - a * c);      // NaN when the line misses: fails every compare
+    // x / a for a = 1 + e, |e| < 1e-6: x - e*x in one rounding (e = a - 1 is exact; the e*e*x left out is 1e-12 x) - a division's result without a division's ten instructions
+    const float e = a - 1.0f, x1 = bh - s, x2 = bh + s;
+    t1 = fmaf(-e, x1, x1); t2 = fmaf(-e, x2, x2);
 }
 __device__ __forceinline__ void strict_sphere_roots(f3 centre, float r2, f3 o, f3 d, float& t1, float& t2) {
     const f3 oc = F3(o.x - centre.x, o.y - centre.y, o.z - centre.z);
@@ -324,7 +330,7 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
                 DISC = fmaf(B, B, -fmaf(co_.z, co_.z, fmaf(co_.y, co_.y, fmaf(co_.x, co_.x, -(G).w))))
 #define RT_SPHERE_TAKE(T1, T2, Q) { bool near_behind = (T1) < tmin; float tc = near_behind ? (T2) : (T1); bool ge = tc >= tmin, le = tc <= closest; \
                 closest = (ge & le) ? tc : closest; best = (ge & (near_behind | le)) ? (Q) : best; }
-#define RT_SPHERE_ROOTS(B, DISC, Q) { float s = big ? sqrt_refined(DISC) : sqrt_fast(DISC); float t1 = (B) - s, t2 = (B) + s; RT_SPHERE_TAKE(t1, t2, Q) }
+#define RT_SPHERE_ROOTS(B, DISC, Q) { float s = sqrt_fast(DISC); float t1 = (B) - s, t2 = (B) + s; RT_SPHERE_TAKE(t1, t2, Q) }
             int i = 0;
             if (EARLY && !big) {   // four spheres per early-out decision: a quarter of the branches, independent discriminants overlap
                 for (; i + 3 < count; i += 4, q += 4 * SLOT_BYTES) {
@@ -344,14 +350,14 @@ __device__ __forceinline__ void closest_hit_runs(const SceneMem<LDS> M, const in
             }
             for (; i < count; ++i, q += SLOT_BYTES) {
                 float4 g = M.ld4(q);
-                if (REF && big) {
-                    float t1, t2; strict_sphere_roots(F3(g), g.w, o, d, t1, t2);
+                if (big) {
+                    float t1, t2;
+                    if (REF) strict_sphere_roots(F3(g), g.w, o, d, t1, t2); else big_sphere_roots(F3(g), g.w, o, d, t1, t2);
                     RT_SPHERE_TAKE(t1, t2, q)
                     continue;
                 }
                 float b, disc;
-                if (big) strict_sphere_coeff(F3(g), g.w, o, d, b, disc);
-                else { RT_SPHERE_DISC(g, b, disc); }
+                { RT_SPHERE_DISC(g, b, disc); }
                 if (EARLY && __builtin_amdgcn_ballot_w64(disc >= 0.0f) == 0ULL) continue;
                 RT_SPHERE_ROOTS(b, disc, q)
             }

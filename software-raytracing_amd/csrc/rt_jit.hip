@@ -47,13 +47,13 @@ std::string lit(float v) {   // exact: hexadecimal floating literal
 }
 std::string v3(const float4& g) { return "F3(" + lit(g.x) + ", " + lit(g.y) + ", " + lit(g.z) + ")"; }
 // opens a block and leaves the roots t1 <= t2 of a sphere slot g = (centre, r*r) (NaN when the line misses);
-// PRIM_SPHERE_BIG: the coefficients in the reference's own operation order and a correctly rounded root (rt_device.h: strict_sphere_coeff; reference arithmetic: strict_sphere_roots)
+// PRIM_SPHERE_BIG: the coefficients in the reference's own operation order and a correctly rounded root (rt_device.h: big_sphere_roots; reference arithmetic: strict_sphere_roots)
 thread_local bool g_gen_ref = false;      // the source being generated is for RT_ARITH_REFERENCE
 std::string sphere_root_source(int type, const float4& g) {
     if (type == PRIM_SPHERE_BIG && g_gen_ref)
         return "    { float t1, t2; strict_sphere_roots(" + v3(g) + ", " + lit(g.w) + ", o, d, t1, t2);";
     if (type == PRIM_SPHERE_BIG)
-        return "    { float b, dq; strict_sphere_coeff(" + v3(g) + ", " + lit(g.w) + ", o, d, b, dq); float s = sqrt_refined(dq); float t1 = b - s, t2 = b + s;";
+        return "    { float t1, t2; big_sphere_roots(" + v3(g) + ", " + lit(g.w) + ", o, d, t1, t2);";
     return "    { f3 co = " + v3(g) + " - o; float b = dot(d, co);\n"
            "      float c = fmaf(co.z, co.z, fmaf(co.y, co.y, fmaf(co.x, co.x, " + lit(-g.w) + ")));\n"
            "      float s = sqrt_fast(fmaf(b, b, -c)); float t1 = b - s, t2 = b + s;";
