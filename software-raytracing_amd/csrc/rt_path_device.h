@@ -166,7 +166,7 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
                     if (degenerate) nd = normalize(nd);
                 }
             }
-            L.d = REF ? strict_dir(nd) : nd;   // unit (REF: as Ray's constructor leaves it, Common/Ray.hpp:33-34): n is unit (slot layout), Reflect/Refract keep the length, the sampled direction is unit by construction
+            L.d = (REF || RT_NORM_DIRS(A)) ? strict_dir(nd) : nd;   // unit (REF: as Ray's constructor leaves it, Common/Ray.hpp:33-34): n is unit (slot layout), Reflect/Refract keep the length, the sampled direction is unit by construction
             if (mtype != MAT_DIELECTRIC) {
                 f3 att = F3(m0);
                 if (VARIANT == 4) att = att * fmaxf(dot(L.d, n), 0.0f);      // 04 Diffuse.hpp:77-78, Metal.hpp:83-84

@@ -1,0 +1,28 @@
+"""Where a fuzz scene's image leaves the oracle's: python3 tools/fuzz_path_px.py seed ...   (FUZZ_FAMILY=b, FUZZ_ARITH=ref as in fuzz_path.py)"""
+import os, sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "software-raytracing_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+from rtamd import abi, lib, scenes
+import orc as oracle
+src = open(os.path.join(ROOT, "tools", "fuzz_path.py")).read().replace("sys.exit(main())", "")
+exec(compile(src, "fuzz_path", "exec"))
+ctx = lib.Context()
+if os.environ.get("FUZZ_ARITH") == "ref": ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_REFERENCE)
+W, H, SPP = 96, 64, 64
+for seed in map(int, sys.argv[1:]):
+    s, cam, variant = (random_scene_b if os.environ.get("FUZZ_FAMILY") == "b" else random_scene)(seed)
+    prm = scenes.path_params(variant, SPP, seed=seed)
+    ctx.set_debug_flags(8)
+    try: g = ctx.render_path(s, cam, prm, W, H)
+    finally: ctx.set_debug_flags(0)
+    o = oracle.render_path(s, cam, prm, W, H, threads=16)
+    G = g["rgb"].reshape(H, W, 3).astype(np.float64); O = (o["sum"] / SPP).reshape(H, W, 3).astype(np.float64)
+    print(f"seed {seed}: means gpu {G.reshape(-1, 3).mean(0)} oracle {O.reshape(-1, 3).mean(0)}; max gpu {G.max():.3g} oracle {O.max():.3g}")
+    d = np.abs(G - O).max(axis=-1)
+    for idx in np.argsort(d.ravel())[::-1][:6]:
+        y, x = divmod(int(idx), W)
+        print(f"   ({x},{y}) gpu {G[y, x]} oracle {O[y, x]}")
+    for i, p in enumerate(s.prims):
+        m = s.materials[p.material]
+        print(f"   prim {i}: type {p.type} {[round(float(v), 3) for v in p.f[:9]]} flags {p.flags} mat type {m.type} albedo {[round(float(a), 2) for a in m.albedo]} rough {m.roughness:.2f} ior {m.refraction_index:.3f}")
