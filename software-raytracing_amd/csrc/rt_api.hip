@@ -58,6 +58,7 @@ struct HostScene {
     std::vector<float4> geom, mats, lights;
     bool path = false;
     bool whitted_branches = false;
+    bool has_strict = false;              // path scenes: some slot is PRIM_*_STRICT (coplanar elements of different arithmetic): hit points are rounded as the reference rounds them
     bool giant_sphere = false;            // path scenes: a sphere of radius > RT_GIANT_SPHERE_RATIO x tMin (rt_device.h): scattered directions are normalised in the reference's order
     std::vector<float4> slots;            // path scenes (variant 3/4): the slot section of rt_device.h
     std::vector<size_t> slot_mat_fixups;  // indices into slots of the B records; B.w holds the material index until upload
@@ -371,6 +372,7 @@ int compile_scene(rt_ctx* c, const rt_scene* s, int variant /*0 whitted, 3, 4*/,
     {
         const char* e = getenv("RT_MI355_STRICT_COPLANAR");
         if (variant != 0 && !(e && e[0] == '0')) strict_flags = find_coplanar(s);
+        for (unsigned char f : strict_flags) H.has_strict = H.has_strict || f != 0;
     }
     auto strict_at = [&](int prim, int face) { return !strict_flags.empty() && strict_flags[(size_t)prim * 6 + face] != 0; };
     for (int i = 0; i < s->n_prims; ++i) {
@@ -939,7 +941,7 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     PathArgs A{};
     A.width = width; A.height = height; A.sample_begin = s0; A.sample_end = s1; A.max_depth = p->max_depth;
     A.jitter = p->spp > 1; A.seed = p->seed; A.t_min = p->t_min; A.t_min_pos = p->t_min > 0.0f ? p->t_min : 1.401298464e-45f; A.t_max = p->t_max;
-    A.debug_flags = c->debug_flags; A.ref_rays = ref ? 1 : 0; A.norm_dirs = H.giant_sphere ? 1 : 0;
+    A.debug_flags = c->debug_flags; A.ref_rays = ref ? 1 : 0; A.norm_dirs = H.giant_sphere ? 1 : 0; A.strict_point = H.has_strict ? 1 : 0;
     // camera code costs about as much as testing 20 primitives: with few primitives wait for a batch of idle lanes,
     // with many refill every idle lane at once (measured: tools/sweep_regen.py, tools/sweep_regen_stress.py)
     A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : ((accel || scene->n_prims >= 128) ? 1 : 16);
@@ -1017,7 +1019,7 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     if (!noalloc && !accel && !(c->debug_flags & (2 | 8)) && !(jit_env && jit_env[0] == '0') && lds_fit &&
         jit_wanted(p->variant, H.slots, H.sruns, (double)width * height * (s1 - s0), (c->debug_flags & 16) || (jit_env && jit_env[0] == '2'), c->jit_note))
         jit = jit_path_kernel(p->variant, H.slots, H.sruns, p->t_min, p->t_max,
-                              (A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : A.sorted ? RT_FORM_SORTED : ref ? (RT_FORM_REGEN | RT_FORM_REF) : RT_FORM_REGEN) | (A.norm_dirs ? RT_FORM_NORM : 0), c->jit_note);
+                              (A.queue ? RT_FORM_QUEUE : A.items ? RT_FORM_ITEMS : A.sorted ? RT_FORM_SORTED : ref ? (RT_FORM_REGEN | RT_FORM_REF) : RT_FORM_REGEN) | (A.norm_dirs ? RT_FORM_NORM : 0) | (A.strict_point ? RT_FORM_POINT : 0), c->jit_note);
     if (noalloc) c->jit_note = "allocation-free entry point: generic kernel";
     if ((rc = begin_timed(c, st, counters))) return rc;      // after a possible compile: kernel_ms is GPU time of the kernels only
     c->last_path_kernel = accel ? 3 : (jit ? 2 : ((size_t)D.total_f4 * 16 <= RT_LDS_SCENE_MAX_BYTES && !(c->debug_flags & 2) ? 1 : 0));

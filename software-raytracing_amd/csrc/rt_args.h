@@ -38,6 +38,7 @@ struct PathArgs {
     int sorted;                     // the outcome-sorted form (path_sorted_body): units belong to workgroups
     int unit_order;                 // item form: order in which the pixel groups are handed out: 0 row-major, 1 bottom-up (last group first)
     int ref_rays;                   // RT_ARITH_REFERENCE: host-side choice of the kernel instantiation (the device code takes it as a template parameter)
+    int strict_point;               // the scene has slots in the reference's operation sequence (coplanar elements): hit points are o + d*t in two roundings, as the reference computes them
     int norm_dirs;                  // the scene has a giant sphere (radius > RT_GIANT_SPHERE_RATIO x tMin): scattered directions are normalised in the reference's operation order
     uint32_t seed;
     float t_min, t_min_pos, t_max;  // t_min_pos = max(t_min, smallest positive float): "t > 0 && t >= tMin" in one compare

@@ -87,6 +87,15 @@ enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLAN
 #else
 #define RT_NORM_DIRS(A) ((A).norm_dirs != 0)
 #endif
+// Scenes with PRIM_*_STRICT slots (coplanar elements of different arithmetic): the hit point is o + d*t in TWO roundings, as the reference computes it (PathArgs::strict_point).
+// Which of two coinciding faces a ray sees is decided by the rounding of two formulas applied to the ray's origin - a hit point; a fused o + d*t lies closer to the face
+// it is on than the reference's, and the decisions downstream stop being the coin flips they are there (a glass box standing on a box: +1.3e-2 scene queries, -1e-4 with it;
+// tools/fuzz_path.py family C, profiles/r03_path_fuzz.txt 11).
+#ifdef RT_JIT_STRICT_POINT
+#define RT_STRICT_POINT(A) (RT_JIT_STRICT_POINT != 0)
+#else
+#define RT_STRICT_POINT(A) ((A).strict_point != 0)
+#endif
 // REF (template parameter of the path kernels' device code, default RT_REF_RAYS): the reference's arithmetic for rays and spheres (see strict_sphere_roots);
 // a scene-specialised build for RT_ARITH_REFERENCE defines RT_REF_RAYS true before this header (rt_jit.hip).
 #ifndef RT_REF_RAYS

@@ -21,5 +21,5 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
 // ray-queue compaction), RT_FORM_ITEMS path_items_body (persistent waves, work counter, lanes decoupled from pixels)
 // RT_FORM_SORTED path_sorted_body (the workgroup sorts its paths by the outcome of the scene query)
 enum { RT_FORM_REGEN = 0, RT_FORM_QUEUE = 1, RT_FORM_ITEMS = 2, RT_FORM_SORTED = 3,
-       RT_FORM_REF = 8, RT_FORM_NORM = 16 };      // flag, with RT_FORM_REGEN only: the reference's arithmetic for rays and spheres (RT_ARITH_REFERENCE; the source defines RT_REF_RAYS true); RT_FORM_NORM: flag, any form: PathArgs::norm_dirs as a literal (RT_JIT_NORM_DIRS)
+       RT_FORM_REF = 8, RT_FORM_NORM = 16, RT_FORM_POINT = 32 };      // flag, with RT_FORM_REGEN only: the reference's arithmetic for rays and spheres (RT_ARITH_REFERENCE; the source defines RT_REF_RAYS true); RT_FORM_NORM: flag, any form: PathArgs::norm_dirs as a literal (RT_JIT_NORM_DIRS); RT_FORM_POINT: likewise PathArgs::strict_point (RT_JIT_STRICT_POINT)
 }

@@ -330,7 +330,7 @@ bool jit_wanted(int variant, const std::vector<float4>& slots, const std::vector
 hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, const std::vector<int4>& sruns, float tmin, float tmax, int form, std::string& note, hipFunction_t* second,
                               const std::vector<int4>* wruns, const std::vector<float4>* wgeom) {
     if (second) *second = nullptr;
-    const bool ref = (form & RT_FORM_REF) != 0, norm = (form & RT_FORM_NORM) != 0;
+    const bool ref = (form & RT_FORM_REF) != 0, norm = (form & RT_FORM_NORM) != 0, point = (form & RT_FORM_POINT) != 0;
     form &= 7;
     if (ref && form != RT_FORM_REGEN) { note = "reference arithmetic: per-lane regeneration only"; return nullptr; }
     const bool whitted = variant == RT_JIT_WHITTED_SOFT || variant == RT_JIT_WHITTED_HARD;
@@ -349,6 +349,7 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     }
     if (ref) defs += "#define RT_REF_RAYS true\n";
     if (!whitted) defs += norm ? "#define RT_JIT_NORM_DIRS 1\n" : "#define RT_JIT_NORM_DIRS 0\n";
+    if (!whitted) defs += point ? "#define RT_JIT_STRICT_POINT 1\n" : "#define RT_JIT_STRICT_POINT 0\n";
     g_gen_ref = ref;
     std::string src = defs + std::string("#define RT_JIT_SCENE 1\ntypedef unsigned int uint32_t; typedef unsigned char uint8_t; typedef unsigned long long uint64_t; typedef unsigned long uintptr_t;\n") + kSrcArgs + "\n" + kSrcDevice + "\n";
     // generation 1 (float compares) is the default: on MI355X it measured 2 % faster than generation 2 (unsigned keys) although

@@ -93,6 +93,42 @@ def random_scene_b(seed):
     elif r < 0.3: s.box(pick(), cam_pos, (3 * scale, 3 * scale, 3 * scale), angles(), flip=True)     # ... inside a box that faces inwards
     return s, scenes.camera(fov, cam_pos, cam_ori), variant
 
+def random_scene_c(seed):
+    """Family C (FUZZ_FAMILY=c): coplanar elements of different arithmetic - boxes resting exactly on the floor plane (turned about the vertical), boxes stacked on boxes,
+    rectangles lying on box tops and on the floor, triangles in the floor plane, a box against a wall; glass among them.  In exact arithmetic those distances tie; the
+    reference decides by the rounding of two formulas, the scene compiler must find every such pair (rt_api.hip find_coplanar) and test it in the reference's sequence."""
+    g = np.random.default_rng(9000 + seed)
+    U = lambda a, b: float(g.uniform(a, b))
+    s = scenes.Scene()
+    variant = abi.RT_PATH_SKY if seed % 2 else abi.RT_PATH_LIGHTS
+    mats = [s.diffuse(tuple(g.uniform(0.2, 0.9, 3))) for _ in range(3)] + [s.metal(tuple(g.uniform(0.5, 0.95, 3)), float(g.choice([0.0, 0.3]))), s.dielectric(0.66), s.dielectric(1.5)]
+    pick = lambda: int(g.choice(mats))
+    if variant == abi.RT_PATH_LIGHTS:
+        floor = -5.0
+        s.plane(pick(), (0, floor, 0), (0, 1, 0)); s.plane(pick(), (0, 5, 0), (0, -1, 0)); s.plane(pick(), (0, 0, -5), (0, 0, 1)); s.plane(pick(), (-5, 0, 0), (1, 0, 0)); s.plane(pick(), (5, 0, 0), (-1, 0, 0))
+        s.rect(s.light_material((15, 15, 15)), (0, 4.95, 0), (3, 3), (90, 0, 0))
+        cam = scenes.camera(90.0, (0, 0, 10), (0, 0, 0)); span, sz = 3.5, (0.8, 2.5)
+    else:
+        floor = -0.5
+        s.plane(pick(), (0, floor, 0), (0, 1, 0))
+        cam = scenes.camera(U(50, 80), (U(-1, 1), U(0.5, 1.5), U(1.5, 3)), (U(-25, -5), U(-20, 20), 0)); span, sz = 2.0, (0.3, 0.9)
+    for _ in range(int(g.integers(1, 4))):
+        w, h, d = U(*sz), U(*sz), U(*sz); x, z = U(-span, span), U(-span, span) - (0 if variant == abi.RT_PATH_LIGHTS else 2.5)
+        yaw = float(g.choice([0.0, 0.0, 90.0, U(-90, 90)]))
+        s.box(pick(), (x, floor + h / 2, z), (w, h, d), (0, yaw, 0))                              # rests on the floor
+        r = g.random()
+        if r < 0.35:
+            h2 = U(*sz) * 0.6; s.box(pick(), (x, floor + h + h2 / 2, z), (w * 0.6, h2, d * 0.6), (0, yaw, 0))      # stacked: shares the top face's plane
+        elif r < 0.6: s.rect(pick(), (x, floor + h, z), (w * 0.7, d * 0.7), (90, yaw, 0))          # a rectangle lying on the top face
+    if g.random() < 0.5: s.rect(pick(), (U(-span, span), floor, U(-span, span)), (U(*sz), U(*sz)), (90, 0, 0))      # a rectangle lying on the floor
+    if g.random() < 0.5:
+        a = np.array([U(-span, span), floor, U(-span, span)])
+        s.triangle(pick(), tuple(a), tuple(a + np.array([U(0.5, 2), 0, U(-1, 1)])), tuple(a + np.array([U(-1, 1), 0, U(0.5, 2)])))    # a triangle in the floor plane
+    if variant == abi.RT_PATH_LIGHTS and g.random() < 0.5:
+        w, h, d = U(*sz), U(*sz), U(*sz); s.box(pick(), (-5 + w / 2, floor + h / 2, U(-3, 3)), (w, h, d), (0, 0, 0))    # in the corner: floor AND wall
+    s.sphere(pick(), (U(-span, span), floor + 0.5 * sz[0], U(-span, span) - (0 if variant == abi.RT_PATH_LIGHTS else 2.5)), 0.5 * sz[0])
+    return s, cam, variant
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -101,7 +137,7 @@ def main():
     W, H, SPP = 96, 64, 64
     bad = 0; worst_q = 0.0; worst_m = 0.0
     for seed in range(first, first + n):
-        s, cam, variant = (random_scene_b if os.environ.get("FUZZ_FAMILY") == "b" else random_scene)(seed)
+        s, cam, variant = {"b": random_scene_b, "c": random_scene_c}.get(os.environ.get("FUZZ_FAMILY", ""), random_scene)(seed)
         prm = scenes.path_params(variant, SPP, seed=seed)
         o = oracle.render_path_px(s, cam, prm, W, H, threads=16)
         line = f"seed {seed:3d} {'03' if variant == abi.RT_PATH_SKY else '04'} prims {len(s.prims):2d} oracle q/s {o['rays'] / (W * H * SPP):8.4f}:"
@@ -127,6 +163,17 @@ def main():
             finally: ctx.set_debug_flags(0)
             same = it["rays"] == st["rays"]
             line += f"  {name} form {ctx.last_path_form()[0]} {'rays=' if same else 'RAYS DIFFER ' + str(it['rays'] - st['rays'])}"
+            if not same: bad += 1; line += " <<<"
+        # the BVH walk against the per-lane brute-force kernel: the same image bit for bit (ties, the tMax rule, strict slots included)
+        if os.environ.get("FUZZ_ARITH") != "ref":
+            ctx.set_debug_flags(8 | 512)
+            try: bf = ctx.render_path(s, cam, prm, W, H)
+            finally: ctx.set_debug_flags(0)
+            ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_BVH)
+            try: bv = ctx.render_path(s, cam, prm, W, H)
+            finally: ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_NONE)
+            same = bv["rays"] == bf["rays"] and np.array_equal(bv["rgb"], bf["rgb"])
+            line += f"  bvh {'bits=' if same else 'DIFFERS rays ' + str(bv['rays'] - bf['rays'])}"
             if not same: bad += 1; line += " <<<"
         print(line, flush=True)
     print(f"largest |rel queries/sample| {worst_q:.2e}, largest rel channel-mean difference {worst_m:.2e}; FAILURES {bad}")
