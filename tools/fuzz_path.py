@@ -129,15 +129,36 @@ def random_scene_c(seed):
     s.sphere(pick(), (U(-span, span), floor + 0.5 * sz[0], U(-span, span) - (0 if variant == abi.RT_PATH_LIGHTS else 2.5)), 0.5 * sz[0])
     return s, cam, variant
 
+def random_scene_d(seed):
+    """Family D (FUZZ_FAMILY=d): 80 ... 1500 primitives - the kernels beyond the scene-specialised builds: LDS-resident with wave-level early-outs (from 64 slots), tiled
+    through LDS (beyond 48 KB) - and the BVH over them.  Small spheres, triangles, rotated rectangles and boxes in a volume, on a floor; both estimators."""
+    g = np.random.default_rng(13000 + seed)
+    U = lambda a, b: float(g.uniform(a, b))
+    s = scenes.Scene()
+    variant = abi.RT_PATH_SKY if seed % 2 else abi.RT_PATH_LIGHTS
+    mats = [s.diffuse(tuple(g.uniform(0.2, 0.9, 3))) for _ in range(4)] + [s.metal(tuple(g.uniform(0.5, 0.95, 3)), float(g.choice([0.0, 0.3]))), s.dielectric(0.66)]
+    pick = lambda: int(g.choice(mats))
+    s.plane(pick(), (0, -2, 0), (0, 1, 0))
+    if variant == abi.RT_PATH_LIGHTS: s.rect(s.light_material((12, 12, 12)), (0, 6, -6), (8, 8), (90, 0, 0))
+    n = int(np.exp(g.uniform(np.log(80), np.log(1500))))
+    for _ in range(n):
+        c = (U(-6, 6), U(-1.8, 4), U(-14, -3)); k = g.random()
+        if k < 0.55: s.sphere(pick(), c, U(0.05, 0.5))
+        elif k < 0.85:
+            a = np.array(c); s.triangle(pick(), tuple(a), tuple(a + g.uniform(-0.8, 0.8, 3)), tuple(a + g.uniform(-0.8, 0.8, 3)))
+        elif k < 0.95: s.rect(pick(), c, (U(0.2, 1.0), U(0.2, 1.0)), (U(-180, 180), U(-180, 180), 0))
+        else: s.box(pick(), c, tuple(g.uniform(0.2, 0.8, 3)), (U(-180, 180), U(-180, 180), 0))
+    return s, scenes.camera(U(50, 80), (U(-1, 1), U(0, 2), U(0, 2)), (U(-15, 5), U(-15, 15), 0)), variant
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     ctx = lib.Context()
     if os.environ.get("FUZZ_ARITH") == "ref": ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_REFERENCE)      # the reference's arithmetic for rays and spheres
-    W, H, SPP = 96, 64, 64
+    W, H, SPP = 96, 64, (16 if os.environ.get("FUZZ_FAMILY") == "d" else 64)
     bad = 0; worst_q = 0.0; worst_m = 0.0
     for seed in range(first, first + n):
-        s, cam, variant = {"b": random_scene_b, "c": random_scene_c}.get(os.environ.get("FUZZ_FAMILY", ""), random_scene)(seed)
+        s, cam, variant = {"b": random_scene_b, "c": random_scene_c, "d": random_scene_d}.get(os.environ.get("FUZZ_FAMILY", ""), random_scene)(seed)
         prm = scenes.path_params(variant, SPP, seed=seed)
         o = oracle.render_path_px(s, cam, prm, W, H, threads=16)
         line = f"seed {seed:3d} {'03' if variant == abi.RT_PATH_SKY else '04'} prims {len(s.prims):2d} oracle q/s {o['rays'] / (W * H * SPP):8.4f}:"
