@@ -942,6 +942,18 @@ static int32_t path_accumulate(rt_ctx* c, const rt_scene* scene, const rt_camera
     A.width = width; A.height = height; A.sample_begin = s0; A.sample_end = s1; A.max_depth = p->max_depth;
     A.jitter = p->spp > 1; A.seed = p->seed; A.t_min = p->t_min; A.t_min_pos = p->t_min > 0.0f ? p->t_min : 1.401298464e-45f; A.t_max = p->t_max;
     A.debug_flags = c->debug_flags; A.ref_rays = ref ? 1 : 0; A.norm_dirs = H.giant_sphere ? 1 : 0; A.strict_point = H.has_strict ? 1 : 0;
+    {   // Refract (Math.hpp:306-312) assumes |d| = 1 and multiplies what |d|^2 is off by with eta^2: harmless through a glass body (in: eta^2, out: 1/eta^2), but a path that refracts
+        // the SAME way many times grows it exponentially (2.8^n at eta = 1/0.6) - and the fast sphere test takes a = d.d as 1.  That happens at the virtual surfaces of the tMax rule
+        // inside a glass sphere wider than tMax (a hit AT tMax, again and again: Common/Ray.hpp:127-134), and through a stack of glass sheets.  The reference normalises every ray;
+        // scenes where this can accumulate do too (fuzz family A at tMax = 12, a glass ground: +2.4 % scene queries without, -1e-6 with; profiles/r03_path_fuzz.txt 14).
+        int sheets = 0;
+        for (int i = 0; i < scene->n_prims && !A.norm_dirs; ++i) {
+            const rt_prim& P = scene->prims[i];
+            if (P.material < 0 || P.material >= scene->n_materials || scene->materials[P.material].type != RT_MAT_DIELECTRIC) continue;
+            if (P.type == RT_PRIM_SPHERE) { if (2.0f * fabsf(P.f[3]) > p->t_max) A.norm_dirs = 1; }
+            else if (P.type != RT_PRIM_BOX && ++sheets >= 4) A.norm_dirs = 1;
+        }
+    }
     // camera code costs about as much as testing 20 primitives: with few primitives wait for a batch of idle lanes,
     // with many refill every idle lane at once (measured: tools/sweep_regen.py, tools/sweep_regen_stress.py)
     A.regen_threshold = c->regen_threshold_override >= 0 ? c->regen_threshold_override : ((accel || scene->n_prims >= 128) ? 1 : 16);
