@@ -159,7 +159,7 @@ def main():
     bad = 0; worst_q = 0.0; worst_m = 0.0
     for seed in range(first, first + n):
         s, cam, variant = {"b": random_scene_b, "c": random_scene_c, "d": random_scene_d}.get(os.environ.get("FUZZ_FAMILY", ""), random_scene)(seed)
-        prm = scenes.path_params(variant, SPP, seed=seed, **({"t_max": float(os.environ["FUZZ_TMAX"])} if os.environ.get("FUZZ_TMAX") else {}))      # FUZZ_TMAX: a short tMax brings the sphere rule 'a hit AT tMax' into play
+        prm = scenes.path_params(variant, SPP, seed=seed, **({"t_max": float(os.environ["FUZZ_TMAX"])} if os.environ.get("FUZZ_TMAX") else {}), **({"t_min": float(os.environ["FUZZ_TMIN"])} if os.environ.get("FUZZ_TMIN") else {}), **({"max_depth": int(os.environ["FUZZ_DEPTH"])} if os.environ.get("FUZZ_DEPTH") else {}))      # FUZZ_TMAX: a short tMax brings the sphere rule 'a hit AT tMax' into play
         o = oracle.render_path_px(s, cam, prm, W, H, threads=16)
         line = f"seed {seed:3d} {'03' if variant == abi.RT_PATH_SKY else '04'} prims {len(s.prims):2d} oracle q/s {o['rays'] / (W * H * SPP):8.4f}:"
         for name, flags in (("generic", 8), ("generated", 16)):

@@ -16,7 +16,7 @@ prims = list(s.prims)
 for keep in sys.argv[2:]:
     idx = [int(k) for k in keep.split(",")]
     s.prims = [prims[i] for i in idx]; s._c = None
-    prm = scenes.path_params(variant, SPP, seed=seed, **({"t_max": float(os.environ["FUZZ_TMAX"])} if os.environ.get("FUZZ_TMAX") else {}))
+    prm = scenes.path_params(variant, SPP, seed=seed, **({"t_max": float(os.environ["FUZZ_TMAX"])} if os.environ.get("FUZZ_TMAX") else {}), **({"t_min": float(os.environ["FUZZ_TMIN"])} if os.environ.get("FUZZ_TMIN") else {}), **({"max_depth": int(os.environ["FUZZ_DEPTH"])} if os.environ.get("FUZZ_DEPTH") else {}))
     ctx.set_debug_flags(8 | int(os.environ.get("FUZZ_XFLAGS", "0")))
     try: g = ctx.render_path(s, cam, prm, W, H)
     finally: ctx.set_debug_flags(0)
