@@ -134,13 +134,14 @@ def _far_small_spheres(n=600):
     return s, scenes.camera(60.0, (0, 5, 20), (-10, 0, 0))
 
 
-def test_reference_arithmetic_for_far_small_spheres(ctx):
+@pytest.mark.parametrize("n_spheres", [300, 600])      # 33 KB of slots and materials: the LDS-resident kernel with early-outs; 67 KB: the LDS-tiled kernel
+def test_reference_arithmetic_for_far_small_spheres(ctx, n_spheres):
     """Small spheres far from where the rays start, 03 estimator at tMin = 0.001: b*b - 4ac cancels from |oc|^2 ~ 1e4 to r^2 ~ 1, so
     the hit point lies up to ~1e-3 inside or outside the surface and the next ray re-hits it or not by rounding.  The fast arithmetic
     traces +0.5...0.9 % more queries than the reference's (documented); RT_ARITH_REFERENCE - directions normalised as
     Ray's constructor does, Ray::intersectsSphere's own operations with a = d.d, hit points rounded as there - follows it to a few 1e-4.
     Also: the option is refused together with the BVH, and switching it back restores the fast kernels' paths."""
-    s, cam = _far_small_spheres()
+    s, cam = _far_small_spheres(n_spheres)
     prm = scenes.path_params(abi.RT_PATH_SKY, 64, max_depth=8, seed=3)
     w, h = 196, 140
     o = oracle.render_path(s, cam, prm, w, h, threads=8)
@@ -149,6 +150,7 @@ def test_reference_arithmetic_for_far_small_spheres(ctx):
     try:
         ref = ctx.render_path(s, cam, prm, w, h)
         assert ctx.last_path_form()[0] == 0                      # one lane per pixel
+        assert ctx.last_path_kernel()[0] == (1 if n_spheres == 300 else 0)
         ctx.set_option(abi.RT_OPT_ACCEL, abi.RT_ACCEL_BVH)
         with pytest.raises(RuntimeError, match="brute force"):
             ctx.render_path(s, cam, prm, w, h)
@@ -158,7 +160,7 @@ def test_reference_arithmetic_for_far_small_spheres(ctx):
     again = ctx.render_path(s, cam, prm, w, h)
     assert again["rays"] == fast["rays"] and np.array_equal(again["rgb"], fast["rgb"])
     assert abs(ref["rays"] / o["rays"] - 1.0) <= 1e-3, ref["rays"] / o["rays"] - 1.0
-    assert 2e-3 <= fast["rays"] / o["rays"] - 1.0 <= 1.5e-2, fast["rays"] / o["rays"] - 1.0      # the documented deviation of the fast arithmetic, pinned
+    if n_spheres == 600: assert 2e-3 <= fast["rays"] / o["rays"] - 1.0 <= 1.5e-2, fast["rays"] / o["rays"] - 1.0      # the documented deviation of the fast arithmetic, pinned
     mo = (o["sum"] / 64).reshape(-1, 3).mean(axis=0)
     assert np.abs(ref["rgb"].reshape(-1, 3).mean(axis=0) / mo - 1.0).max() <= 1e-3
 
