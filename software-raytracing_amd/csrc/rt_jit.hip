@@ -302,7 +302,8 @@ uint64_t fnv1a(const std::string& s) {
     return h;
 }
 
-struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn2 = nullptr; std::string note; };      // fn2: the 02 module's second kernel (stage 2 of the wavefront form)
+struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn2 = nullptr; std::string note; uint64_t last_use = 0; };      // fn2: the 02 module's second kernel (stage 2 of the wavefront form)
+uint64_t g_tick = 0;                                   // one per lookup (under g_mu): the clock of the least-recently-used replacement
 std::mutex g_mu;
 std::map<std::pair<int, uint64_t>, Entry> g_cache;   // (device, source hash)
 
@@ -310,9 +311,15 @@ std::map<std::pair<int, uint64_t>, Entry> g_cache;   // (device, source hash)
 
 // When to pay the ~0.7 s compile: a scene that is rendered once at example size would lose by it, a scene that is rendered
 // again (progressive / interactive use, benchmarks) or for seconds wins.  So: compile on the SECOND render of the same
-// scene in this process, or at once when the job is large or the caller forces it; never for more than RT_JIT_MAX_SCENES
-// distinct scenes per process (an animation would compile every frame).
+// scene in this process, or at once when the job is large or the caller forces it.  At most RT_JIT_MAX_SCENES compiled scenes are kept per process
+// (RT_MI355_JIT_MAX_SCENES=<n> overrides, 1..4096).  When the table is full the least recently used kernel of this device makes room - but only if it has not been
+// used for 4 x the capacity in lookups: a long-lived process that moves on to new scenes keeps specialising, a process that cycles through more scenes than fit
+// does not recompile on every render (0.7 s each) but runs the newcomers on the generic kernels, as before.
 constexpr size_t RT_JIT_MAX_SCENES = 64;
+size_t jit_capacity() {
+    static const size_t n = [] { const char* e = getenv("RT_MI355_JIT_MAX_SCENES"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 4096 ? (size_t)v : RT_JIT_MAX_SCENES; }();
+    return n;
+}
 constexpr double RT_JIT_BIG_JOB_SAMPLES = 5e10;
 std::map<uint64_t, int> g_sightings;
 
@@ -388,8 +395,19 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
     const auto key = std::make_pair(dev, fnv1a(src));
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
-    if (it != g_cache.end()) { note = it->second.note; if (second) *second = it->second.fn2; return it->second.fn; }
-    if (g_cache.size() >= RT_JIT_MAX_SCENES) { note = "more than " + std::to_string(RT_JIT_MAX_SCENES) + " distinct scenes in this process: generic kernel"; return nullptr; }
+    ++g_tick;
+    if (it != g_cache.end()) { it->second.last_use = g_tick; note = it->second.note; if (second) *second = it->second.fn2; return it->second.fn; }
+    if (g_cache.size() >= jit_capacity()) {
+        auto lru = g_cache.end();
+        for (auto e = g_cache.begin(); e != g_cache.end(); ++e)
+            if (e->first.first == dev && (lru == g_cache.end() || e->second.last_use < lru->second.last_use)) lru = e;
+        if (lru == g_cache.end() || g_tick - lru->second.last_use < 4 * jit_capacity()) {
+            note = "more than " + std::to_string(jit_capacity()) + " distinct scenes in use in this process: generic kernel"; return nullptr; }
+        // nothing of that module can still be running once the device is idle; its last launch was >= 4 x capacity renders ago (a caller launches what it was handed
+        // before it asks again, and any other caller would have to fit that many lookups - compiles among them - between being handed the kernel and launching it)
+        if (lru->second.mod) { (void)hipDeviceSynchronize(); (void)hipModuleUnload(lru->second.mod); }
+        g_cache.erase(lru);
+    }
     Entry e;
     // RT_MI355_JIT_CACHE=<directory>: compiled code objects are kept there across processes, keyed by the hash of the generated source and the
     // hiprtc version (a serving process or a render farm pays the ~0.7 s compile once per scene and compiler, not once per process).  Off unless set:
@@ -447,6 +465,7 @@ hipFunction_t jit_path_kernel(int variant, const std::vector<float4>& slots, con
         }
         hiprtcDestroyProgram(&prog);
     }
+    e.last_use = g_tick;
     g_cache[key] = e;
     note = e.note;
     if (second) *second = e.fn2;

@@ -41,3 +41,16 @@ def test_jit_cache_on_disk(ctx, tmp_path):
     assert runs[0]["kernel"] == runs[1]["kernel"] == 2
     assert runs[0]["sha"] == runs[1]["sha"] and runs[0]["rays"] == runs[1]["rays"]
     assert runs[1]["first_render_s"] < 0.5 * runs[0]["first_render_s"], runs
+
+
+@pytest.mark.gpu
+def test_jit_table_replaces_stale_kernels(ctx):
+    """The table of compiled scenes (rt_jit.hip: 64 per process, here 2) replaces its least recently used kernel when that one is stale, and leaves newcomers
+    on the generic kernel while every resident kernel is in use - a long-lived process keeps specialising new scenes, a cycle through too many does not
+    recompile per render.  tests/jit_lru_child.py renders three scenes in a fixed order and reports the kernel kind of every render."""
+    env = dict(os.environ, RT_MI355_JIT_MAX_SCENES="2")
+    env.pop("RT_MI355_JIT", None); env.pop("RT_MI355_JIT_CACHE", None)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "jit_lru_child.py")], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kinds = json.loads(r.stdout.strip().splitlines()[-1])["kinds"]
+    assert kinds == [2, 2, 1] + [2] * 8 + [2, 1, 2, 2], kinds
