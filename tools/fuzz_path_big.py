@@ -15,7 +15,7 @@ tot_g = tot_o = 0
 for seed in map(int, sys.argv[1:]):
     if seed == 0: s, cam, prm = scenes.scene03(SPP, seed=7)
     else:
-        s, cam, variant = {"b": random_scene_b, "c": random_scene_c, "d": random_scene_d}.get(os.environ.get("FUZZ_FAMILY", ""), random_scene)(seed); prm = scenes.path_params(variant, SPP, seed=seed, **({"t_max": float(os.environ["FUZZ_TMAX"])} if os.environ.get("FUZZ_TMAX") else {}), **({"t_min": float(os.environ["FUZZ_TMIN"])} if os.environ.get("FUZZ_TMIN") else {}), **({"max_depth": int(os.environ["FUZZ_DEPTH"])} if os.environ.get("FUZZ_DEPTH") else {}))
+        s, cam, variant = FAMILIES[os.environ.get("FUZZ_FAMILY", "")](seed); prm = scenes.path_params(variant, SPP, seed=seed, **({"t_max": float(os.environ["FUZZ_TMAX"])} if os.environ.get("FUZZ_TMAX") else {}), **({"t_min": float(os.environ["FUZZ_TMIN"])} if os.environ.get("FUZZ_TMIN") else {}), **({"max_depth": int(os.environ["FUZZ_DEPTH"])} if os.environ.get("FUZZ_DEPTH") else {}))
     ctx.set_debug_flags(flags)
     try: g = ctx.render_path(s, cam, prm, W, H)
     finally: ctx.set_debug_flags(0)

@@ -19,7 +19,7 @@ def rel(s, cam, prm):
     o = oracle.render_path(s, cam, prm, W, H, threads=16)
     return (g["rays"] - o["rays"]) / o["rays"], o["rays"] / (W * H * SPP)
 for seed in map(int, sys.argv[1:]):
-    s, cam, variant = {"b": random_scene_b, "c": random_scene_c, "d": random_scene_d}.get(os.environ.get("FUZZ_FAMILY", ""), random_scene)(seed)
+    s, cam, variant = FAMILIES[os.environ.get("FUZZ_FAMILY", "")](seed)
     prm = scenes.path_params(variant, SPP, seed=seed, **({"t_max": float(os.environ["FUZZ_TMAX"])} if os.environ.get("FUZZ_TMAX") else {}), **({"t_min": float(os.environ["FUZZ_TMIN"])} if os.environ.get("FUZZ_TMIN") else {}), **({"max_depth": int(os.environ["FUZZ_DEPTH"])} if os.environ.get("FUZZ_DEPTH") else {}))
     r, q = rel(s, cam, prm)
     print(f"seed {seed}: whole scene rel q {r:+.2e} (oracle {q:.4f} queries/sample); camera {list(cam.position)} {list(cam.orientation_deg)} fov {cam.fov_deg:.1f}")

@@ -11,7 +11,7 @@ ctx = lib.Context()
 if os.environ.get("FUZZ_ARITH") == "ref": ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_REFERENCE)
 W, H, SPP = 96, 64, int(os.environ.get("FUZZ_SPP", "64"))
 seed = int(sys.argv[1])
-s, cam, variant = {"b": random_scene_b, "c": random_scene_c, "d": random_scene_d}.get(os.environ.get("FUZZ_FAMILY", ""), random_scene)(seed)
+s, cam, variant = FAMILIES[os.environ.get("FUZZ_FAMILY", "")](seed)
 prims = list(s.prims)
 for keep in sys.argv[2:]:
     idx = [int(k) for k in keep.split(",")]

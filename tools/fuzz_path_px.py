@@ -11,7 +11,7 @@ ctx = lib.Context()
 if os.environ.get("FUZZ_ARITH") == "ref": ctx.set_option(abi.RT_OPT_ARITHMETIC, abi.RT_ARITH_REFERENCE)
 W, H, SPP = 96, 64, 64
 for seed in map(int, sys.argv[1:]):
-    s, cam, variant = {"b": random_scene_b, "c": random_scene_c, "d": random_scene_d}.get(os.environ.get("FUZZ_FAMILY", ""), random_scene)(seed)
+    s, cam, variant = FAMILIES[os.environ.get("FUZZ_FAMILY", "")](seed)
     prm = scenes.path_params(variant, SPP, seed=seed, **({"t_max": float(os.environ["FUZZ_TMAX"])} if os.environ.get("FUZZ_TMAX") else {}), **({"t_min": float(os.environ["FUZZ_TMIN"])} if os.environ.get("FUZZ_TMIN") else {}), **({"max_depth": int(os.environ["FUZZ_DEPTH"])} if os.environ.get("FUZZ_DEPTH") else {}))
     ctx.set_debug_flags(8)
     try: g = ctx.render_path(s, cam, prm, W, H)

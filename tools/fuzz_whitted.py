@@ -9,26 +9,10 @@ import numpy as np
 from rtamd import lib, scenes
 import orc as oracle
 
-K = float(os.environ.get("FUZZ_SCALE", "1"))      # the whole scene times K (the kernels' tMin and shadow offsets stay: other conditioning)
-def random_scene(seed):
-    g = np.random.default_rng(seed)
-    s = scenes.Scene()
-    mats = []
-    for _ in range(int(g.integers(2, 5))):
-        r2r = float(g.choice([1.0, 1.0, 0.0, 0.5])) if seed % 3 else float(g.choice([1.0, 0.0]))     # every third seed: chains only
-        mats.append(s.phong(tuple(g.uniform(0.1, 1.0, 3)), float(g.uniform(0, 1)), float(g.choice([1, 2, 8, 16, 50, 64.5, 300, 1000])),
-                            float(g.choice([1.0, 0.8, 0.4, 0.0])), r2r, float(g.choice([1.0, 0.7, 1.5]))))
-    pick = lambda: int(g.choice(mats + ([-1] if g.random() < 0.1 else [])))
-    s.plane(pick(), (0, K * float(g.uniform(-5, -2)), 0), (0, 1, 0))
-    if g.random() < 0.6: s.plane(pick(), (0, 0, K * float(g.uniform(-40, -20))), (float(g.uniform(-.3, .3)), float(g.uniform(-.3, .3)), 1))
-    for _ in range(int(g.integers(1, 6))):
-        s.sphere(pick(), (K * float(g.uniform(-6, 6)), K * float(g.uniform(-2, 4)), K * float(g.uniform(-18, -6))), K * float(g.uniform(0.5, 3)))
-    for _ in range(int(g.integers(0, 3))):
-        v = g.uniform(-8, 8, (3, 3)); v[:, 2] = g.uniform(-22, -8, 3)
-        s.triangle(pick(), *[tuple(map(float, r * K)) for r in v])
-    for _ in range(int(g.integers(1, 4))):
-        s.light((K * float(g.uniform(-10, 10)), K * float(g.uniform(3, 12)), K * float(g.uniform(-10, 4))), tuple(g.uniform(0.2, 0.9, 3)), K * float(g.uniform(0.3, 2.0)))
-    return s, scenes.camera(float(g.uniform(40, 90))), int(g.integers(1, 7)), int(g.choice([0, 0, 1, 3, 8]))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from fuzz_scenes import random_whitted_scene      # noqa: E402
+K = float(os.environ.get("FUZZ_SCALE", "1"))      # the whole scene times K
+def random_scene(seed): return random_whitted_scene(seed, K)
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
