@@ -206,7 +206,7 @@ int32_t rt_abi_version(void);
  *                             reference's own operation sequence, because there those bits decide OFTEN.
  *   RT_ARITH_REFERENCE:       every ray direction normalised as Ray's constructor does (Common/Ray.hpp:33-34), every sphere
  *                             tested with Ray::intersectsSphere's own operations (Common/Ray.hpp:105-121: a = d.d, true
- *                             divisions, correctly rounded root), hit points rounded as the reference rounds them.  For scenes
+ *                             divisions, correctly rounded root), sphere normals and hit points rounded as the reference rounds them.  For scenes
  *                             of small spheres far from where the rays start (|o - c| >> r) at a small tMin, where a ray
  *                             re-hits the surface it leaves at a rate the rounding sets: scene queries per sample then follow
  *                             the reference to ~3e-4 instead of ~1e-2.  Costs about 40 % on 03; brute force and one lane per

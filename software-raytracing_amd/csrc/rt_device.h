@@ -262,6 +262,9 @@ __device__ __forceinline__ void strict_sphere_roots(f3 centre, float r2, f3 o, f
     const float s = sqrt_refined(bh * bh - a * c);      // NaN when the line misses: fails every compare
     t1 = (bh - s) / a; t2 = (bh + s) / a;
 }
+// 1 / |v| as math::Normalize computes it (Common/Math.hpp:233-238: the length in the reference's operation order, then a division per component - here one reciprocal
+// by true division; the per-component quotients v/len and v*(1/len) differ in the last bit at most)
+__device__ __forceinline__ float strict_inv_length(f3 v) { return 1.0f / sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z); }
 // origin + direction * t as the reference rounds it (product, then sum; Common/Ray.hpp, the hit records of the scene elements)
 __device__ __forceinline__ f3 strict_point(f3 o, f3 d, float t) { return F3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t); }
 // Ray::intersectsPlane (Common/Ray.hpp:223-249).  Slot: G = (n, -), A = (p0, 0).
