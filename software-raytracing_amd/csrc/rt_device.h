@@ -79,7 +79,7 @@ enum { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_RECT = 2, PRIM_TRI = 3, PRIM_AAPLAN
 #define RT_BIG_SPHERE_RATIO 30000.0f
 // A GIANT sphere (radius > RT_GIANT_SPHERE_RATIO x tMin; r = 300 at 03's tMin): every bounce off or inside it is decided by rounding (c = oc.oc - r*r carries noise of
 // r*r*2^-24, i.e. distances of r*2^-25/cos(theta) against tMin), and what the roots are then depends on the last bits of the direction: in scenes that have one, scattered
-// directions are normalised in the reference's operation order (PathArgs::norm_dirs; strict_dir).  Measured on fuzz family B (tools/fuzz_path.py, profiles/r03_path_fuzz.txt 9):
+// directions are normalised in the reference's operation order (PathArgs::norm_dirs; strict_dir), and the sphere normal and the hit point follow it too.  Measured on fuzz family B (tools/fuzz_path.py, profiles/r03_path_fuzz.txt 9):
 // a glass ground of r = 2500: +37 % scene queries without, -0.6 % with; r = 10000 ... 50000: +2 ... 3 % -> 0.2 %.  Nothing the reference ships is near it.
 #define RT_GIANT_SPHERE_RATIO 300000.0f
 #ifdef RT_JIT_NORM_DIRS

@@ -315,7 +315,7 @@ std::map<std::pair<int, uint64_t>, Entry> g_cache;   // (device, source hash)
 // (RT_MI355_JIT_MAX_SCENES=<n> overrides, 1..4096).  When the table is full the least recently used kernel of this device makes room - but only if it has not been
 // used for 4 x the capacity in lookups: a long-lived process that moves on to new scenes keeps specialising, a process that cycles through more scenes than fit
 // does not recompile on every render (0.7 s each) but runs the newcomers on the generic kernels, as before.
-constexpr size_t RT_JIT_MAX_SCENES = 64;
+constexpr size_t RT_JIT_MAX_SCENES = 256;      // ~100 KB of code object each
 size_t jit_capacity() {
     static const size_t n = [] { const char* e = getenv("RT_MI355_JIT_MAX_SCENES"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 4096 ? (size_t)v : RT_JIT_MAX_SCENES; }();
     return n;

@@ -90,10 +90,10 @@ __device__ __forceinline__ void shade(const SceneMem<LDS> M, const PathArgs& A, 
         // hit record (03 Sphere.hpp:57-73; 04 Scene/Sphere.hpp:58-74, Plane.hpp:55-66, Rectangle.hpp:79-92), one
         // formula for every primitive type (slot layout, rt_device.h): n = (p - c)*k + m, turned against the ray
         float4 sa = M.ld4(hit + SLOT_A), sb = M.ld4(hit + SLOT_B), sc = M.ld4(hit + SLOT_C);
-        L.o = (REF || RT_STRICT_POINT(A)) ? strict_point(L.o, L.d, t) : madd(L.d, t, L.o);      // the hit point is the next origin; nothing below needs the old one
+        L.o = (REF || RT_STRICT_POINT(A) || RT_NORM_DIRS(A)) ? strict_point(L.o, L.d, t) : madd(L.d, t, L.o);      // the hit point is the next origin; nothing below needs the old one
         f3 pc = L.o - F3(sa);
         // spheres: Normalize(p - c) (k = +-1; also right when the hit was reported at tMax, off the surface); others: k = 0
-        float k = REF ? (sa.w != 0.0f ? sa.w * strict_inv_length(pc) : 0.0f) : sa.w * rsq_fast(fmaf(pc.z, pc.z, fmaf(pc.y, pc.y, fmaf(pc.x, pc.x, 1e-30f))));
+        float k = (REF || RT_NORM_DIRS(A)) ? (sa.w != 0.0f ? sa.w * strict_inv_length(pc) : 0.0f) : sa.w * rsq_fast(fmaf(pc.z, pc.z, fmaf(pc.y, pc.y, fmaf(pc.x, pc.x, 1e-30f))));
         f3 n = madd(pc, k, F3(sb));
         float facing = dot(L.d, madd(pc, k, F3(sc)));
         bool back = facing > 0.0f;

@@ -45,7 +45,7 @@ def test_jit_cache_on_disk(ctx, tmp_path):
 
 @pytest.mark.gpu
 def test_jit_table_replaces_stale_kernels(ctx):
-    """The table of compiled scenes (rt_jit.hip: 64 per process, here 2) replaces its least recently used kernel when that one is stale, and leaves newcomers
+    """The table of compiled scenes (rt_jit.hip: 256 per process, here 2) replaces its least recently used kernel when that one is stale, and leaves newcomers
     on the generic kernel while every resident kernel is in use - a long-lived process keeps specialising new scenes, a cycle through too many does not
     recompile per render.  tests/jit_lru_child.py renders three scenes in a fixed order and reports the kernel kind of every render."""
     env = dict(os.environ, RT_MI355_JIT_MAX_SCENES="2")

@@ -33,7 +33,7 @@ def main():
             d = np.abs(gpu["rgb"].astype(np.float64) - o["rgb"])
             npx = int((d.max(axis=-1) > 0).sum()); dmax = float(d.max())
             t = totals.setdefault(name, [0, 0, 0.0]); t[0] += npx; t[1] += W * H; t[2] = max(t[2], dmax)
-            form = "w" if samples > 0 and ctx.last_whitted_form() == 1 else "m"      # w: wavefront form (weighted sum, within 4e-7; the library compiles at most 64 scenes per process, later ones run the generic kernels)
+            form = "w" if samples > 0 and ctx.last_whitted_form() == 1 else "m"      # w: wavefront form (weighted sum, within 4e-7; the library compiled at most 64 scenes per process then (256 now), later ones run the generic kernels)
             line += f"  {name} k{ctx.last_whitted_kernel()}{form} {'rays=' if same_rays else 'RAYS DIFFER'} px {npx} max {dmax:.2e}"
             if not same_rays or dmax > 1e-3: bad += 1
         print(line, flush=True)
