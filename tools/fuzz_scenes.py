@@ -145,6 +145,31 @@ def random_scene_d(seed):
     return s, scenes.camera(U(50, 80), (U(-1, 1), U(0, 2), U(0, 2)), (U(-15, 5), U(-15, 15), 0)), variant
 
 
+def random_scene_e(seed):
+    """Family E: the 04 estimator (lights, tMin 0.01) on a ground SPHERE of radius 100 ... 10000 under a light rectangle and a light sphere - big and giant spheres with
+    the estimator whose attenuation carries the cosine; objects as in family A."""
+    g = np.random.default_rng(21000 + seed)
+    U = lambda a, b: float(g.uniform(a, b))
+    s = scenes.Scene()
+    mats = [s.diffuse(tuple(g.uniform(0.1, 0.9, 3))) for _ in range(int(g.integers(1, 4)))]
+    mats += [s.metal(tuple(g.uniform(0.5, 0.95, 3)), float(g.choice([0.0, 0.2, 1.0]))) for _ in range(int(g.integers(0, 3)))]
+    if g.random() < 0.6: mats.append(s.dielectric(float(g.choice([0.6, 0.66, 1.5]))))
+    pick = lambda: int(g.choice(mats))
+    R = float(g.choice([100.0, 1000.0, 10000.0]))
+    s.sphere(pick(), (0, -5.0 - R, 0), R)
+    lm = s.light_material(tuple(g.uniform(6, 20, 3)))
+    s.rect(lm, (U(-2, 2), 6.0, U(-2, 2)), (U(3, 8), U(3, 8)), (90, 0, 0))
+    if g.random() < 0.5: s.sphere(lm, (U(-6, 6), U(0, 4), U(-6, 2)), U(0.5, 1.5))
+    for _ in range(int(g.integers(2, 6))):
+        kind = g.choice(["sphere", "sphere", "box", "rect", "tri"])
+        P = (U(-4, 4), U(-4.5, 2), U(-4, 4))
+        if kind == "sphere": s.sphere(pick(), P, U(0.5, 2.0))
+        elif kind == "box": s.box(pick(), P, tuple(g.uniform(0.5, 3.0, 3)), (0, U(-180, 180), 0))
+        elif kind == "rect": s.rect(pick(), P, (U(1, 4), U(1, 4)), (U(-180, 180), U(-180, 180), 0))
+        else:
+            a = np.array(P); s.triangle(pick(), tuple(a), tuple(a + g.uniform(-3, 3, 3)), tuple(a + g.uniform(-3, 3, 3)))
+    return s, scenes.camera(U(60, 100), (U(-1, 1), U(-1, 2), 10), (U(-10, 5), U(-8, 8), 0)), abi.RT_PATH_LIGHTS
+
 def random_whitted_scene(seed, K=1.0):
     """Whitted scene (01 / 02): -> (scene, camera, max_depth, shadow_samples); K scales the whole scene (the kernels' tMin and shadow offsets stay)."""
     g = np.random.default_rng(seed)
@@ -167,4 +192,4 @@ def random_whitted_scene(seed, K=1.0):
     return s, scenes.camera(float(g.uniform(40, 90))), int(g.integers(1, 7)), int(g.choice([0, 0, 1, 3, 8]))
 
 
-FAMILIES = {"": random_scene, "a": random_scene, "b": random_scene_b, "c": random_scene_c, "d": random_scene_d}
+FAMILIES = {"": random_scene, "a": random_scene, "b": random_scene_b, "c": random_scene_c, "d": random_scene_d, "e": random_scene_e}
