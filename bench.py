@@ -113,7 +113,13 @@ def main():
     if rehearsal:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    # BENCH_ONE_RANK_COLLECTIVE=1 (with --gpus 1): run the N > 1 step - pack, RCCL all-reduce, unpack - as written, over a ONE-rank
+    # RCCL communicator, so that the `nccl` branch executes on a one-GPU box too.  Its line is marked; the driver never sets it.
+    one_rank_collective = world == 1 and os.environ.get("BENCH_ONE_RANK_COLLECTIVE") == "1"
+    if one_rank_collective:
+        os.environ.setdefault("MASTER_PORT", "29531")
+    collective = world > 1 or one_rank_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not rehearsal and torch.cuda.device_count() < world:      # fail loudly, never fold ranks onto fewer devices
             raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} GPU(s) to rank {rank}")
@@ -139,7 +145,7 @@ def main():
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
     bgra = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
     # the collective carries the three data floats of a pixel, packed (99.5 MB at 4K), not the float4 accumulator (132.7 MB)
-    rgb = torch.zeros(H * W, 3, dtype=torch.float32, device="cuda") if world > 1 else None
+    rgb = torch.zeros(H * W, 3, dtype=torch.float32, device="cuda") if collective else None
     torch.cuda.synchronize()
     empty_share = shard.is_empty((s_begin, s_end))
     # Host wait between render and collective: only in the one-GPU rehearsal (BENCH_HOST_SYNC=1 forces it, =0 removes it).
@@ -155,7 +161,7 @@ def main():
             else:
                 ctx.path_accumulate_device(s, cam, prm, W, H, accum.data_ptr(), sp)
             ev[1].record(stream)
-            if world > 1:
+            if collective:
                 if host_sync:
                     ctx.sync(sp)
                 a4 = accum.view(H * W, 4)
@@ -170,7 +176,7 @@ def main():
             ev[4].record(stream)
 
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,7 +186,7 @@ def main():
     os.environ["RT_MI355_JIT"] = "2"          # the documented switch: specialise at the first render of a scene
     if args.warmup == 0:
         ctx.render_path(s, cam, scenes.path_params(abi.RT_PATH_LIGHTS, 1, seed=1), 16, 16)
-    if world > 1:                             # the communicator's lazy set-up (RCCL: rings, IPC handles) is one-time too
+    if collective:                            # the communicator's lazy set-up (RCCL: rings, IPC handles) is one-time too
         with torch.cuda.stream(stream):
             dist.all_reduce(torch.zeros(1024, dtype=torch.float32, device="cuda"), op=dist.ReduceOp.SUM)
     for _ in range(args.warmup):
@@ -199,13 +205,13 @@ def main():
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     r = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
     dt = float(t.item()); rays_step = float(r.item())
     ph = torch.tensor(np.mean(phases, axis=0), dtype=torch.float64, device="cuda")
     per_rank = torch.tensor([float(rays), float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if collective:
         gathered = [torch.zeros_like(per_rank) for _ in range(world)]
         dist.all_gather(gathered, per_rank)
         ph_max = ph.clone(); dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
@@ -249,11 +255,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"04_PathTracingLights scene (5 planes, 3 spheres, 1 emissive rectangle), {W}x{H}, {SPP} spp, max depth 6, seed 1",
                        "jit_compiler": jit_compiler, "samples_per_step": W * H * SPP, "rays_per_step": rays_step, "samples_per_sec": W * H * SPP * args.steps / dt,
-                       "parallelism": (f"sample-range x{world}, one all-reduce(sum) of the packed RGB sums ({W * H * 12 / 1e6:.1f} MB)" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")) if world > 1 else "single GPU",
+                       "parallelism": (f"sample-range x{world}, one all-reduce(sum) of the packed RGB sums ({W * H * 12 / 1e6:.1f} MB)" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "") + (" [ONE-RANK RCCL communicator: BENCH_ONE_RANK_COLLECTIVE=1]" if one_rank_collective else "")) if collective else "single GPU",
                        "rays_per_rank": [int(g[0].item()) for g in gathered], "kernel_ms_per_rank": [round(float(g[1].item()), 3) for g in gathered],
                        "phase_ms_rank0": {"render": round(float(ph[0]), 3), "pack": round(float(ph[1]), 3), "allreduce": round(float(ph[2]), 3), "unpack_resolve": round(float(ph[3]), 3)},
                        "phase_ms_max_over_ranks": {"render": round(float(ph_max[0]), 3), "pack": round(float(ph_max[1]), 3), "allreduce": round(float(ph_max[2]), 3), "unpack_resolve": round(float(ph_max[3]), 3)},
-                       "host_sync_before_collective": bool(host_sync and world > 1)},
+                       "host_sync_before_collective": bool(host_sync and collective)},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": traffic, "traffic_source": ("profiles/r03_pmc_hbm_traffic.json: separate rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE), not this run; algorithmic bytes are 16 B/pixel = 132.7 MB" if traffic is not None else None),
                          "kernel": kernel_name, "kernel_ms": k_ms, "kernel_ms_steps": [round(x, 3) for x in kernel_ms], "flops_per_ray": fpr, "rays_per_launch": rays,
@@ -263,7 +269,7 @@ def main():
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline_reference(W, H, SPP, threads) or cpu_baseline(scenes, W, H, SPP, args.cpu_rows, threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 
