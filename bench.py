@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--watchdog", type=int, default=900, help="seconds after which a run that is still going prints every thread's stack and exits (0 = off): a rank stuck in a collective must not hang the job")
     args = ap.parse_args()
 
+    # this pool's host driver supports only dmabuf IPC: without it RCCL's cross-process handles fail (hipIpcGetMemHandle: invalid
+    # argument).  The launcher exports it already; kept here so that a rank started from a bare environment behaves the same
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # the image's own compiler library in place of the older one PyTorch bundles (rtamd/lib.py; +3 % on the generated kernel)
     from rtamd import lib as _lib_early
     jit_compiler = _lib_early.prefer_system_compiler()
