@@ -63,3 +63,21 @@ def test_two_ranks_reproduce_the_single_process_frame(tmp_path):
     assert np.allclose(acc[:, :, :3], full["sum"], rtol=2e-6, atol=1e-6)
     a = oracle.resolve(acc[:, :, :3], float(SPP), 1); b = oracle.resolve(full["sum"], float(SPP), 1)
     assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a == full["bgra"]).mean() > 0.999
+
+
+def _bench(args, env_extra):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_refuses_a_launch_that_does_not_match_gpus():
+    """bench.py must not fold an N-GPU request onto fewer ranks, and has no CPU path to time: non-zero exit and a message, no JSON line."""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})                      # started bare: WORLD_SIZE is 1
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "--nproc-per-node 2" in r.stderr and r.stdout.strip() == ""
+    r = _bench(["--gpus", "1", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+    if not torch.cuda.is_available():
+        r = _bench(["--steps", "1", "--warmup", "0"], {})
+        assert r.returncode != 0 and "needs an MI355X" in r.stderr and r.stdout.strip() == ""
